@@ -1,0 +1,237 @@
+/*
+ * ebcsim.h — C ABI of libebcsim.so, the MI355X-native batched crowd-navigation
+ * simulator that replaces the simulation hot path of kolomeytsev/EB-CADRL.
+ *
+ * The reference has no FFI: its boundary is the duck-typed Python surface of
+ * simulator/env.py (EntityBasedCollisionAvoidance).  Every entry point below
+ * names the reference interface (file:line under the reference tree) it stands
+ * in for.  The binding a maintainer of the reference would add is the ctypes
+ * stub shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch types; every function returns EBC_OK (0) or a negative
+ *     EbcStatus; the message of the last failure on the calling thread is
+ *     ebc_last_error().
+ *   - the caller owns every buffer it passes; the library owns the opaque
+ *     handle and the device allocations behind it.
+ *   - buffers are either all host or all device per call (`location`).  Host
+ *     buffers are staged through the handle's own device buffers and the call
+ *     returns after the copy-back; device buffers are used in place and the
+ *     call only enqueues work on the handle's stream (ebc_synchronize waits).
+ *   - batched layout is struct-of-arrays.  E = n_envs, N = max_humans (row
+ *     stride of every per-human array, humans in the reference's type-major
+ *     order adults, bicycles, children: simulator/env.py:393), S = max_static,
+ *     R = N + S observation rows, T = 13 (+4 with agent type) rotated width.
+ *   - simulator state is IEEE double (the reference keeps Python floats:
+ *     simulator/agents/agent.py:164-228); ORCA runs in float exactly where the
+ *     third-party rvo2 library does; rotated observations are float where the
+ *     reference builds them with torch.Tensor (rl/policy/cadrl.py:236-337).
+ *   - there is no CPU fallback: without a HIP device ebc_create fails.
+ */
+#ifndef EBCSIM_H
+#define EBCSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EBC_ABI_VERSION 1
+
+typedef enum EbcStatus {
+  EBC_OK = 0,
+  EBC_ERR_INVALID = -1,     /* bad argument (NULL, size, range)            */
+  EBC_ERR_UNSUPPORTED = -2, /* valid in the reference, not built here      */
+  EBC_ERR_DEVICE = -3,      /* HIP runtime error or no device              */
+  EBC_ERR_STATE = -4        /* call order (e.g. step before reset)         */
+} EbcStatus;
+
+/* simulator/utils/utils.py:9-14 (AgentType) */
+enum { EBC_ADULT = 0, EBC_BICYCLE = 1, EBC_CHILD = 2, EBC_ADULT_STATIC = 3, EBC_ROBOT = 4 };
+
+/* Info subclass identity, simulator/utils/info.py, in the priority order of
+ * Reward.compute (simulator/utils/reward.py:103-179). */
+enum {
+  EBC_INFO_NOTHING = 0,
+  EBC_INFO_DANGER = 1,
+  EBC_INFO_REACH_GOAL = 2,
+  EBC_INFO_COLLISION_OBSTACLE = 3,
+  EBC_INFO_COLLISION_ADULT = 4,
+  EBC_INFO_COLLISION_BICYCLE = 5,
+  EBC_INFO_COLLISION_CHILD = 6,
+  EBC_INFO_TIMEOUT = 7
+};
+
+/* robot kinematics: Agent.kinematics (simulator/agents/agent.py:21, :164-188).
+ * HOLONOMIC takes ActionXY(vx, vy); UNICYCLE takes ActionRot(v, r).  ActionXYRot
+ * cannot pass compute_collision_agent_with_robot (simulator/utils/collisions.py
+ * :41-42 reads action.v) and is therefore not part of the path. */
+enum { EBC_HOLONOMIC = 0, EBC_UNICYCLE = 1 };
+
+enum { EBC_HOST = 0, EBC_DEVICE = 1 };
+
+/* who moves the humans this step (simulator/policy/policy_factory.py:10-14) */
+enum {
+  EBC_HUMAN_EXTERNAL = 0, /* velocities given by ebc_set_human_actions (BASELINE config 2) */
+  EBC_HUMAN_LINEAR = 1,   /* simulator/policy/linear.py:17-23 */
+  EBC_HUMAN_ORCA = 2,     /* simulator/policy/orca.py:85-157 (+ rvo2) */
+  EBC_HUMAN_CACHED = 3    /* re-use the velocities the last ebc_lookahead computed for the same state */
+};
+
+enum {
+  EBC_ROBOT_EXTERNAL = 0, /* robot_action[E][2] supplied */
+  EBC_ROBOT_LINEAR = 1    /* simulator/policy/linear.py:17-23 applied to the robot, on device */
+};
+
+/* flags */
+enum {
+  EBC_FLAG_AUTO_RESET = 1, /* an env whose previous step was terminal restarts from its reset() scene */
+  EBC_FLAG_BORDER = 2      /* border[4] valid: simulator/env.py:264-271 */
+};
+
+/* Everything env.configure() / Reward.__init__ / ORCA.__init__ read from the INI
+ * files (simulator/env.py:58-87, simulator/utils/reward.py:18-75,
+ * simulator/policy/orca.py:58-69) plus the two policy-side switches rotate()
+ * consults (rl/policy/cadrl.py:261, :304).  A missing optional key of the
+ * reference (value None) is NaN here. */
+typedef struct EbcParams {
+  uint32_t struct_size; /* = sizeof(EbcParams), checked */
+  int32_t robot_kinematics;
+  int32_t robot_visible;     /* [robot] visible: humans see the robot (env.py:401-402) */
+  int32_t new_reward;        /* reward.py:19 */
+  double time_step;          /* [env] time_step */
+  double time_limit;         /* [env] time_limit (getint) */
+  double map_size_m;         /* [map] map_size_m */
+  double map_resolution;     /* [map] map_resolution */
+  double time_max;           /* reward.py:20 (NaN when absent) */
+  double time_good;          /* reward.py:25 */
+  double max_goal_distance;  /* reward.py:21 (NaN when absent: goal_reward None) */
+  double success_reward;     /* reward.py:26 */
+  double collision_penalty[4]; /* adult, bicycle, child, obstacle: reward.py:27-38 */
+  double discomfort_dist[3];   /* adult, bicycle, child: reward.py:40-50 */
+  double discomfort_factor[3]; /* adult, bicycle, child: reward.py:52-68 */
+  double rotation_penalty_factor; /* reward.py:70 */
+  double orca_safety_space;  /* orca.py:63 */
+  float orca_neighbor_dist;  /* orca.py:64 */
+  float orca_time_horizon;   /* orca.py:66 */
+  int32_t orca_max_neighbors; /* orca.py:65 */
+  int32_t with_agent_type;   /* sarl.py:103-110: T = 17 instead of 13 */
+  int32_t rotate_unicycle;   /* policy kinematics == "unicycle": cadrl.py:261 */
+  int32_t reserved;
+} EbcParams;
+
+/* Scene rows for ebc_reset: the outputs of SceneGenerator (simulator/scene/
+ * scene_generator.py:330-378, :807-863) for n envs, all host pointers.
+ * Per-human arrays are [n][N], per-static arrays [n][S], the grid is [n][G][2]
+ * 64-bit words (G = round(map_size_m / map_resolution) <= 128): bit y of row x
+ * set <=> scene.map[x, y] == 0 (occupied).  grid may be NULL (free map). */
+typedef struct EbcScene {
+  uint32_t struct_size;
+  int32_t n;
+  const int32_t *n_humans;   /* [n] */
+  const double *px, *py, *vx, *vy, *gx, *gy, *radius, *v_pref; /* [n][N] */
+  const uint8_t *type;       /* [n][N] AgentType */
+  const int32_t *n_static;   /* [n] (may be NULL when S == 0) */
+  const double *spx, *spy, *sradius; /* [n][S] static_obstacles_as_pedestrians */
+  const uint64_t *grid;      /* [n][G][2] or NULL */
+  const double *robot;       /* [n][9] px,py,vx,vy,radius,gx,gy,v_pref,theta (FullState order, state.py:1-12) */
+} EbcScene;
+
+/* One env.step(action, update=True) for every env (simulator/env.py:388-466). */
+typedef struct EbcStepArgs {
+  uint32_t struct_size;
+  int32_t location;     /* of every pointer below */
+  int32_t human_policy;
+  int32_t robot_policy;
+  int32_t flags;
+  int32_t reserved;
+  const double *robot_action; /* [E][2] ActionXY(vx,vy) or ActionRot(v,r); NULL with EBC_ROBOT_LINEAR */
+  const double *border;       /* host [4] = x_lo, x_hi, y_lo, y_hi (always host) */
+  /* outputs, each may be NULL */
+  double *reward;       /* [E] */
+  uint8_t *done;        /* [E] */
+  uint8_t *info;        /* [E] EBC_INFO_* */
+  double *dmin;         /* [E][3] dmin_adult, dmin_bicycle, dmin_child (inf when none) */
+  double *dist_to_goal; /* [E] */
+  double *robot_action_out; /* [E][2] the action applied (for EBC_ROBOT_LINEAR) */
+  double *human_action; /* [E][N][2] velocities the humans chose this step */
+  double *ob;           /* [E][R][5] px,py,vx,vy,radius of the returned ob list (env.py:381-382, :457-458) */
+  float *obs_rotated;   /* [E][R][T] rotate(robot full state + ob row), cadrl.py:236-337 */
+} EbcStepArgs;
+
+/* The |A|-way env.onestep_lookahead sweep of MultiHumanRL.predict
+ * (rl/policy/multi_human_rl.py:38-61) with humans evaluated once. */
+typedef struct EbcLookaheadArgs {
+  uint32_t struct_size;
+  int32_t location;
+  int32_t human_policy; /* LINEAR, ORCA or EXTERNAL */
+  int32_t n_actions;    /* A */
+  int32_t flags;
+  int32_t reserved;
+  const double *actions; /* [A][2], shared by all envs (cadrl.py:91-116) */
+  const double *border;  /* host [4] or NULL */
+  double *reward;        /* [E][A] */
+  uint8_t *done;         /* [E][A] */
+  uint8_t *info;         /* [E][A] */
+  double *dmin;          /* [E][A][3] or NULL */
+  double *next_ob;       /* [E][R][5] get_next_observable_state rows (env.py:449-458) or NULL */
+  float *rows_rotated;   /* [E][A][R][T] rotate(propagate(robot, a) + next row) or NULL */
+} EbcLookaheadArgs;
+
+/* Read-back of the simulator state (env.states / Agent.get_full_state). */
+typedef struct EbcStateView {
+  uint32_t struct_size;
+  int32_t location;
+  double *px, *py, *vx, *vy, *gx, *gy, *radius, *v_pref; /* [E][N], each may be NULL */
+  uint8_t *type;         /* [E][N] */
+  int32_t *n_humans;     /* [E] */
+  double *robot;         /* [E][9] FullState order */
+  double *global_time;   /* [E] env.global_time */
+  double *arrival_time;  /* [E][N] adult_times / bicycle_times / children_times (env.py:365-378) */
+  uint8_t *done;         /* [E] latched terminal flag */
+} EbcStateView;
+
+int ebc_abi_version(void);
+const char *ebc_last_error(void);
+
+/* Defaults of the reference (ORCA constants orca.py:58-69, time_good reward.py:25). */
+int ebc_params_default(EbcParams *p);
+
+/* gym.make + env.configure + env.set_robot: simulator/__init__.py:4-7,
+ * simulator/env.py:58-92.  Allocates device state for E envs on HIP device
+ * `device_id`. */
+int ebc_create(int device_id, int n_envs, int max_humans, int max_static,
+               const EbcParams *params, void **handle_out);
+int ebc_destroy(void *handle);
+
+/* Run the handle's work on an existing HIP stream (e.g. torch's current
+ * stream) so the caller's events order with it.  NULL = the handle's own. */
+int ebc_set_stream(void *handle, void *hip_stream);
+int ebc_synchronize(void *handle);
+
+/* env.reset for the listed envs (simulator/env.py:128-205): uploads the scene
+ * rows, zeroes global_time and arrival times (env.py:149-151) and keeps a copy
+ * for EBC_FLAG_AUTO_RESET.  env_ids NULL = envs 0..n-1. */
+int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *scene);
+
+/* Humans moved by the host (BASELINE config 2): act[E][N][2]. */
+int ebc_set_human_actions(void *handle, int location, const double *act);
+
+int ebc_step(void *handle, const EbcStepArgs *args);
+int ebc_lookahead(void *handle, const EbcLookaheadArgs *args);
+int ebc_get_state(void *handle, const EbcStateView *view);
+
+/* Geometry of the handle (E, N, S, T, G). */
+int ebc_dims(void *handle, int32_t out[5]);
+
+/* Timing aid for bench.py: average device milliseconds per ebc_step kernel
+ * launch since the last call with reset != 0, measured with HIP events on the
+ * stream the kernel runs on.  Enabled by ebc_timing(handle, 1). */
+int ebc_timing(void *handle, int enable);
+int ebc_timing_read(void *handle, int reset, double *avg_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBCSIM_H */

@@ -1,0 +1,274 @@
+"""ctypes wrapper of the CPU checker (oracle/libebc_oracle.so).
+
+TEST INFRASTRUCTURE, NOT PRODUCT: only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg import this module.  ORCA parity is unpinned (see
+ebc_oracle.h); everything else is pinned by tests/golden/.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.join(os.path.dirname(_HERE), "eb-cadrl_amd")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+
+from ebcsim import _abi  # noqa: E402  (struct layouts of include/ebcsim.h)
+
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libebc_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        d, i = C.c_double, C.c_int
+        pd = C.POINTER(C.c_double)
+        L.orc_point_to_segment_dist.restype = d
+        L.orc_point_to_segment_dist.argtypes = [d] * 6
+        L.orc_collision_agent_robot.restype = i
+        L.orc_collision_agent_robot.argtypes = [d] * 9 + [i] + [d] * 3 + [pd]
+        L.orc_grid_collision.restype = i
+        L.orc_grid_collision.argtypes = [C.c_void_p, i, d, d, d, d, d, C.c_void_p]
+        L.orc_reward.restype = None
+        L.orc_reward.argtypes = [C.c_void_p, C.c_void_p, d, d, d, C.c_void_p, C.c_void_p,
+                                 pd, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), pd]
+        L.orc_linear.restype = None
+        L.orc_linear.argtypes = [d] * 5 + [pd, pd]
+        L.orc_orca.restype = None
+        L.orc_orca.argtypes = [C.c_void_p] + [d] * 8 + [i] + [C.c_void_p] * 5 + [pd, pd]
+        L.orc_rvo2_agent0.restype = None
+        L.orc_rvo2_agent0.argtypes = [C.c_float, C.c_float, i, C.c_float, C.c_void_p, C.c_void_p,
+                                      C.c_float, C.c_float, C.c_void_p, i, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+        L.orc_rotate_row.restype = None
+        L.orc_rotate_row.argtypes = [C.c_void_p, i, i, C.c_void_p]
+        L.orc_propagate_robot.restype = None
+        L.orc_propagate_robot.argtypes = [C.c_void_p, i, d, d, d, C.c_void_p]
+        L.orc_step.restype = i
+        L.orc_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_lookahead.restype = i
+        L.orc_lookahead.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class OrcState(C.Structure):
+    _fields_ = [("E", C.c_int32), ("N", C.c_int32), ("S", C.c_int32), ("G", C.c_int32)] + [
+        (k, C.c_void_p) for k in (
+            "n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
+            "n_static", "spx", "spy", "sradius", "grid", "robot", "global_time",
+            "arrival_time", "done", "human_action", "px0", "py0", "vx0", "vy0", "robot0")
+    ]
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+# ---- scalar entry points (used by the golden-vector tests) -------------------
+
+def point_to_segment_dist(x1, y1, x2, y2, x3, y3):
+    return lib().orc_point_to_segment_dist(x1, y1, x2, y2, x3, y3)
+
+
+def collision_agent_robot(h, r, kinematics, action, dt, dmin):
+    """h = (px,py,vx,vy,radius); r = (px,py,theta,radius) -> (dmin, collision)"""
+    dm = C.c_double(dmin)
+    c = lib().orc_collision_agent_robot(h[0], h[1], h[2], h[3], h[4], r[0], r[1], r[2], r[3],
+                                        kinematics, action[0], action[1], dt, C.byref(dm))
+    return dm.value, bool(c)
+
+
+def grid_collision(grid, G, map_size_m, map_resolution, px, py, radius, border=None):
+    g = None if grid is None else np.ascontiguousarray(grid, dtype=np.uint64)
+    b = None if border is None else np.ascontiguousarray(border, dtype=np.float64)
+    return bool(lib().orc_grid_collision(_ptr(g), G, map_size_m, map_resolution, px, py, radius,
+                                         _ptr(b)))
+
+
+def reward(params, robot, action, global_time, dmin, coll):
+    robot = np.ascontiguousarray(robot, dtype=np.float64)
+    dmin = np.ascontiguousarray(dmin, dtype=np.float64)
+    coll = np.ascontiguousarray(coll, dtype=np.int32)
+    rw, dg = C.c_double(), C.c_double()
+    dn, inf = C.c_uint8(), C.c_uint8()
+    lib().orc_reward(C.addressof(params), _ptr(robot), action[0], action[1], global_time,
+                     _ptr(dmin), _ptr(coll), C.byref(rw), C.byref(dn), C.byref(inf), C.byref(dg))
+    return rw.value, bool(dn.value), int(inf.value), dg.value
+
+
+def linear(px, py, gx, gy, v_pref):
+    vx, vy = C.c_double(), C.c_double()
+    lib().orc_linear(px, py, gx, gy, v_pref, C.byref(vx), C.byref(vy))
+    return vx.value, vy.value
+
+
+def orca(params, self_state, others):
+    """self_state = (px,py,vx,vy,radius,gx,gy,v_pref); others [m][5] px,py,vx,vy,radius"""
+    o = np.ascontiguousarray(others, dtype=np.float64).reshape(-1, 5)
+    cols = [np.ascontiguousarray(o[:, k]) for k in range(5)]
+    vx, vy = C.c_double(), C.c_double()
+    lib().orc_orca(C.addressof(params), *[float(x) for x in self_state], len(o),
+                   *[_ptr(c) for c in cols], C.byref(vx), C.byref(vy))
+    return vx.value, vy.value
+
+
+def rvo2_agent0(time_step, neighbor_dist, max_neighbors, time_horizon, pos, vel, radius,
+                max_speed0, pref0):
+    """pos/vel [n][2], radius [n] float32 state of an rvo2 simulator; returns agent 0's new velocity."""
+    pos = np.ascontiguousarray(pos, dtype=np.float32)
+    vel = np.ascontiguousarray(vel, dtype=np.float32)
+    radius = np.ascontiguousarray(radius, dtype=np.float32)
+    pref0 = np.ascontiguousarray(pref0, dtype=np.float32)
+    out = np.zeros(2, np.float32)
+    lib().orc_rvo2_agent0(time_step, neighbor_dist, max_neighbors, time_horizon, pos[0].ctypes.data,
+                          vel[0].ctypes.data, float(radius[0]), max_speed0, pref0.ctypes.data,
+                          len(pos) - 1, pos[1:].ctypes.data, vel[1:].ctypes.data,
+                          radius[1:].ctypes.data, out.ctypes.data)
+    return float(out[0]), float(out[1])
+
+
+def rotate_rows(rows15, with_agent_type, rotate_unicycle):
+    rows15 = np.ascontiguousarray(rows15, dtype=np.float64).reshape(-1, 15)
+    T = 17 if with_agent_type else 13
+    out = np.zeros((len(rows15), T), dtype=np.float32)
+    L = lib()
+    for k in range(len(rows15)):
+        L.orc_rotate_row(rows15[k].ctypes.data, int(with_agent_type), int(rotate_unicycle),
+                         out[k].ctypes.data)
+    return out
+
+
+def propagate_robot(robot, kinematics, action, dt):
+    robot = np.ascontiguousarray(robot, dtype=np.float64)
+    out = np.zeros(9)
+    lib().orc_propagate_robot(_ptr(robot), kinematics, action[0], action[1], dt, _ptr(out))
+    return out
+
+
+# ---- batched environment --------------------------------------------------------
+
+class OracleEnv:
+    """Same call surface as ebcsim.BatchedEnv, computed by the scalar C restatement."""
+
+    def __init__(self, params, n_envs, max_humans, max_static):
+        self.params = params
+        self.E, self.N, self.S = n_envs, max_humans, max_static
+        self.G = int(round(params.map_size_m / params.map_resolution))
+        self.T = _abi.rot_width(params)
+        self.R = self.N + self.S
+        E, N, S = self.E, self.N, max(self.S, 1)
+        f = lambda *s: np.zeros(s, dtype=np.float64)  # noqa: E731
+        self.a = dict(
+            n_humans=np.zeros(E, np.int32), px=f(E, N), py=f(E, N), vx=f(E, N), vy=f(E, N),
+            gx=f(E, N), gy=f(E, N), radius=f(E, N), v_pref=f(E, N),
+            type=np.zeros((E, N), np.uint8), n_static=np.zeros(E, np.int32),
+            spx=f(E, S), spy=f(E, S), sradius=f(E, S),
+            grid=np.zeros((E, self.G, 2), np.uint64), robot=f(E, 9), global_time=f(E),
+            arrival_time=f(E, N), done=np.zeros(E, np.uint8), human_action=f(E, N, 2),
+            px0=f(E, N), py0=f(E, N), vx0=f(E, N), vy0=f(E, N), robot0=f(E, 9))
+        self.has_grid = False
+        self._st = OrcState()
+
+    def _state(self):
+        st = self._st
+        st.E, st.N, st.S, st.G = self.E, self.N, self.S, self.G
+        for k, v in self.a.items():
+            setattr(st, k, v.ctypes.data)
+        if not self.has_grid:
+            st.grid = None
+        return st
+
+    def reset(self, scene, env_ids=None):
+        ids = np.arange(scene.n) if env_ids is None else np.asarray(env_ids)
+        a = self.a
+        for k in ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type"):
+            a[k][ids] = getattr(scene, k)
+        a["n_humans"][ids] = scene.n_humans
+        if self.S:
+            a["n_static"][ids] = scene.n_static
+            a["spx"][ids], a["spy"][ids], a["sradius"][ids] = scene.spx, scene.spy, scene.sradius
+        if scene.grid is not None:
+            a["grid"][ids] = scene.grid
+            self.has_grid = True
+        else:
+            a["grid"][ids] = 0
+        a["robot"][ids] = scene.robot
+        a["global_time"][ids] = 0
+        a["arrival_time"][ids] = 0
+        a["done"][ids] = 0
+        for k in ("px", "py", "vx", "vy"):
+            a[k + "0"][ids] = a[k][ids]
+        a["robot0"][ids] = a["robot"][ids]
+
+    def set_human_actions(self, act):
+        self.a["human_action"][...] = np.asarray(act, dtype=np.float64).reshape(self.E, self.N, 2)
+
+    def step(self, robot_action=None, human_policy=_abi.HUMAN_ORCA,
+             robot_policy=_abi.ROBOT_EXTERNAL, flags=0, border=None):
+        E, N, R, T = self.E, self.N, self.R, self.T
+        out = dict(reward=np.zeros(E), done=np.zeros(E, np.uint8), info=np.zeros(E, np.uint8),
+                   dmin=np.zeros((E, 3)), dist_to_goal=np.zeros(E),
+                   robot_action_out=np.zeros((E, 2)), human_action=np.zeros((E, N, 2)),
+                   ob=np.zeros((E, R, 5)), obs_rotated=np.zeros((E, R, T), np.float32))
+        args = _abi.EbcStepArgs()
+        args.struct_size = C.sizeof(args)
+        args.location = _abi.HOST
+        args.human_policy, args.robot_policy = human_policy, robot_policy
+        if robot_action is not None:
+            ra = np.ascontiguousarray(robot_action, dtype=np.float64).reshape(E, 2)
+            args.robot_action = ra.ctypes.data
+        if border is not None:
+            b = np.ascontiguousarray(border, dtype=np.float64).reshape(4)
+            args.border = b.ctypes.data
+            flags |= _abi.FLAG_BORDER
+        args.flags = flags
+        for k, v in out.items():
+            setattr(args, k, v.ctypes.data)
+        rc = lib().orc_step(C.addressof(self.params), C.addressof(self._state()), C.addressof(args))
+        if rc != 0:
+            raise RuntimeError("orc_step failed: %d" % rc)
+        return out
+
+    def lookahead(self, actions, human_policy=_abi.HUMAN_ORCA, flags=0, border=None,
+                  want_rows=True):
+        actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(-1, 2)
+        A, E, R, T = len(actions), self.E, self.R, self.T
+        out = dict(reward=np.zeros((E, A)), done=np.zeros((E, A), np.uint8),
+                   info=np.zeros((E, A), np.uint8), dmin=np.zeros((E, A, 3)),
+                   next_ob=np.zeros((E, R, 5)))
+        if want_rows:
+            out["rows_rotated"] = np.zeros((E, A, R, T), np.float32)
+        args = _abi.EbcLookaheadArgs()
+        args.struct_size = C.sizeof(args)
+        args.location = _abi.HOST
+        args.human_policy, args.n_actions = human_policy, A
+        args.actions = actions.ctypes.data
+        if border is not None:
+            b = np.ascontiguousarray(border, dtype=np.float64).reshape(4)
+            args.border = b.ctypes.data
+            flags |= _abi.FLAG_BORDER
+        args.flags = flags
+        for k, v in out.items():
+            setattr(args, k, v.ctypes.data)
+        rc = lib().orc_lookahead(C.addressof(self.params), C.addressof(self._state()),
+                                 C.addressof(args))
+        if rc != 0:
+            raise RuntimeError("orc_lookahead failed: %d" % rc)
+        return out
+
+    def get_state(self):
+        keys = ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type", "n_humans",
+                "robot", "global_time", "arrival_time", "done")
+        return {k: self.a[k].copy() for k in keys}

@@ -1,0 +1,102 @@
+"""Shared helpers for the parity tests: fixture loading and scene/params rebuilds."""
+import json
+import os
+
+import numpy as np
+
+from ebcsim import _abi, config as ebc_config
+from ebcsim.scene import SceneBatch, pack_grid
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def params_of(z, key="params"):
+    return ebc_config.params_from_dict(json.loads(str(z[key])))
+
+
+def batch_from_init(z, prefix="init_", copies=1, max_humans=None, max_static=None):
+    """SceneBatch from the init_* arrays a trajectory fixture stores (one scene, tiled)."""
+    n = len(z[prefix + "px"])
+    st = z[prefix + "static"].reshape(-1, 3)
+    N = max_humans or n
+    S = max_static if max_static is not None else len(st)
+    f = lambda *s: np.zeros(s)  # noqa: E731
+    b = SceneBatch(copies, N, S, np.full(copies, n, np.int32), f(copies, N), f(copies, N),
+                   f(copies, N), f(copies, N), f(copies, N), f(copies, N), f(copies, N),
+                   f(copies, N), np.zeros((copies, N), np.uint8),
+                   np.full(copies, len(st), np.int32), f(copies, max(S, 1)), f(copies, max(S, 1)),
+                   f(copies, max(S, 1)), None, f(copies, 9))
+    for k in ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type"):
+        getattr(b, k)[:, :n] = z[prefix + k]
+    if len(st):
+        b.spx[:, :len(st)], b.spy[:, :len(st)], b.sradius[:, :len(st)] = st.T
+    grid = z[prefix + "grid"]
+    if grid.any():
+        b.grid = np.repeat(pack_grid(1.0 - grid)[None], copies, axis=0)
+    b.robot[:] = z[prefix + "robot"]
+    return b
+
+
+HUMAN_POLICY = {"linear": _abi.HUMAN_LINEAR}
+
+
+def human_policy_of(z):
+    meta = json.loads(str(z["meta"]))
+    return _abi.HUMAN_LINEAR if meta["human_policy"] == "linear" else _abi.HUMAN_ORCA
+
+
+TRAJ_PINNED = ["traj_a5_linear", "traj_a5_scripted", "traj_a3b3s2_scripted", "traj_n10_walls_t17",
+               "traj_unicycle_rotpen"]
+TRAJ_ORCASUB = ["traj_a5_linear_orcasub", "traj_a5_scripted_orcasub",
+                "traj_a3b3s2_scripted_orcasub", "traj_n10_walls_t17_orcasub"]
+
+
+def check_trajectory(env, z, atol=1e-9, rot_atol=1e-5, lookahead=True):
+    """Replay fixture `z` on `env` (OracleEnv or BatchedEnv; env 0 is compared; every env of
+    the batch gets the same scene and actions) and assert parity step by step."""
+    pol = human_policy_of(z)
+    E = env.E
+    n = len(z["init_px"])
+    ns = len(z["init_static"].reshape(-1, 3))
+    la_steps = list(z["la_step"]) if ("la_step" in z.files and lookahead) else []
+    for t in range(len(z["action"])):
+        if t in la_steps:
+            k = la_steps.index(t)
+            la = env.lookahead(z["la_actions"], human_policy=pol)
+            np.testing.assert_array_equal(la["done"][0].astype(bool), z["la_done"][k].astype(bool))
+            np.testing.assert_array_equal(la["info"][0], z["la_info"][k])
+            np.testing.assert_allclose(la["reward"][0], z["la_reward"][k], atol=atol, rtol=0)
+            np.testing.assert_allclose(la["next_ob"][0][:n + ns], z["la_next_ob"][k][:, :5],
+                                       atol=atol, rtol=0)
+            np.testing.assert_allclose(la["rows_rotated"][0][:, :n + ns], z["la_rows"][k],
+                                       atol=rot_atol, rtol=rot_atol)
+        act = np.tile(z["action"][t], (E, 1))
+        out = env.step(robot_action=act, human_policy=pol)
+        msg = "step %d" % t
+        assert bool(out["done"][0]) == bool(z["done"][t]), msg
+        assert int(out["info"][0]) == int(z["info"][t]), msg
+        np.testing.assert_allclose(out["reward"][0], z["reward"][t], atol=atol, rtol=0, err_msg=msg)
+        np.testing.assert_allclose(out["dmin"][0], z["dmin"][t], atol=atol, rtol=0, err_msg=msg)
+        if not np.isnan(z["dist_to_goal"][t]):
+            np.testing.assert_allclose(out["dist_to_goal"][0], z["dist_to_goal"][t], atol=atol,
+                                       rtol=0, err_msg=msg)
+        np.testing.assert_allclose(out["human_action"][0][:n], z["human_action"][t], atol=atol,
+                                   rtol=0, err_msg=msg)
+        np.testing.assert_allclose(out["ob"][0][:n + ns], z["ob"][t][:, :5], atol=atol, rtol=0,
+                                   err_msg=msg)
+        np.testing.assert_allclose(out["obs_rotated"][0][:n + ns], z["rot"][t], atol=rot_atol,
+                                   rtol=rot_atol, err_msg=msg)
+        st = env.get_state()
+        np.testing.assert_allclose(st["robot"][0], z["robot"][t], atol=atol, rtol=0, err_msg=msg)
+        np.testing.assert_allclose(st["global_time"][0], z["time"][t], atol=1e-12, rtol=0)
+        np.testing.assert_allclose(st["arrival_time"][0][:n], z["arrival"][t], atol=1e-12, rtol=0,
+                                   err_msg=msg)
+        hum = np.stack([st["px"][0][:n], st["py"][0][:n], st["vx"][0][:n], st["vy"][0][:n]], 1)
+        np.testing.assert_allclose(hum, z["humans"][t], atol=atol, rtol=0, err_msg=msg)
+        if E > 1:  # every replica of the scene must agree with env 0
+            for key in ("reward", "info", "obs_rotated"):
+                assert (out[key] == out[key][0:1]).all(), msg
