@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — agent-steps/s of the simulation hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 500 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one ebc_step launch over the rank's scene batch: ORCA for every human,
+kinematics, swept collisions, grid window, reward, rotated observation — inputs resident in
+HBM, outputs left in HBM.  Scenes are independent, so ranks own disjoint env slices and the
+data path has no collective (weak scaling: per-GPU batch fixed); torch.distributed (RCCL) only
+carries the barrier and the max-over-ranks of the timing.
+
+Prints ONE JSON line (rank 0): metric/value/unit + roofline + cpu_baseline.
+"""
+import argparse
+import configparser
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "eb-cadrl_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+WORKLOADS = {
+    # name: (env config, policy config, envs per GPU)
+    "metric": ("bench_metric.config", "policy_agent_type.config", 4096),
+    "cfg2": ("bench_cfg2.config", "policy_plain.config", 4096),
+    "cfg3": ("bench_metric.config", "policy_agent_type.config", 16384),
+    "cfg4": ("bench_cfg2.config", "policy_plain.config", 16384),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_env_step(N, S, T):
+    """fp32-SoA accounting the roofline is priced against."""
+    reads = 32 * N + 44 + 16 * S + 24
+    writes = 16 * N + 20 + 18 + 4 * T * (N + S)
+    return reads + writes
+
+
+def build_batch(workload, envs, first_env):
+    from ebcsim import config as ebc_config, scene as ebc_scene
+    env_cfg, pol_cfg, _ = WORKLOADS[workload]
+    cfg = configparser.RawConfigParser()
+    cfg.read(os.path.join(PKG, "configs", env_cfg))
+    pol = configparser.RawConfigParser()
+    pol.read(os.path.join(PKG, "configs", pol_cfg))
+    params = ebc_config.params_from_config(cfg, pol)
+    sc = ebc_scene.SceneConfig.from_config(cfg)
+    base = 2000 if "metric" in env_cfg else 1000
+    scenes = [ebc_scene.generate_scene(sc, base + first_env + e) for e in range(envs)]
+    return params, ebc_scene.SceneBatch.from_scenes(scenes)
+
+
+def cpu_baseline(params, batch, seconds_target=12.0):
+    """The CPU oracle (scalar C restatement, 1 thread) on a bounded sample of the same workload."""
+    from ebcsim import _abi, scene as ebc_scene
+    from oracle import oracle
+    n = min(256, batch.n)
+    sub = ebc_scene.SceneBatch(n, batch.N, batch.S, *[
+        None if getattr(batch, k) is None else getattr(batch, k)[:n] for k in (
+            "n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
+            "n_static", "spx", "spy", "sradius", "grid", "robot")])
+    env = oracle.OracleEnv(params, n, batch.N, batch.S)
+    env.reset(sub)
+    flags = _abi.FLAG_AUTO_RESET
+    env.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=flags)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(10):
+            env.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=flags)
+        steps += 10
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or steps >= 100000:
+            break
+    humans = int(sub.n_humans.sum())
+    return {"value": humans * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d humans x %d steps of the same workload, oracle/ebc_oracle.c, "
+                      "1 thread, %.1f s" % (n, batch.N, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
+    ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--human-policy", default="orca", choices=["orca", "linear"],
+                    help="diagnostic only: the headline metric is ORCA")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ebcsim import _abi
+    from ebcsim.batched import BatchedEnv
+
+    E = args.envs or WORKLOADS[args.workload][2]
+    params, batch = build_batch(args.workload, E, first_env=rank * E)
+    env = BatchedEnv(params, E, batch.N, batch.S, device=local_rank)
+    env.reset(batch)
+    env.use_torch_stream()
+    outs = env.alloc_step_outputs(("reward", "done", "info", "obs_rotated"))
+    flags = _abi.FLAG_AUTO_RESET
+    hp = _abi.HUMAN_ORCA if args.human_policy == "orca" else _abi.HUMAN_LINEAR
+    kw = dict(human_policy=hp, robot_policy=_abi.ROBOT_LINEAR, flags=flags)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        env.step_device(outs, **kw)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        env.step_device(outs, **kw)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stream_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on
+
+    # per-launch kernel duration: HIP events around every launch, in a separate untimed pass
+    env.timing(True)
+    for _ in range(min(args.steps, 200)):
+        env.step_device(outs, **kw)
+    kernel_ms, n_timed = env.timing_read(reset=True)
+    env.timing(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    humans = torch.tensor([float(batch.n_humans.sum())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(humans, op=dist.ReduceOp.SUM)
+    elapsed_max = float(t.item())
+    total_humans = float(humans.item())
+
+    if rank == 0:
+        S_mean = float(batch.n_static.mean()) if batch.S else 0.0
+        bytes_launch = algorithmic_bytes_per_env_step(batch.N, S_mean, env.T) * E
+        achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "agent-steps/sec", "value": total_humans * args.steps / elapsed_max,
+            "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: %d envs/GPU x %d humans + %d static rows, ORCA + kinematics + "
+                                   "collisions + reward + rotated obs (T=%d) in one HIP launch per step, "
+                                   "auto-reset%s" % (args.workload, E, batch.N, batch.S, env.T,
+                                                   "" if hp == _abi.HUMAN_ORCA else " [DIAGNOSTIC: linear humans]"),
+                       "envs_per_gpu": E, "humans": int(batch.N), "parallelism": "env-slice x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "step_kernel<ORCA>", "kernel_ms": kernel_ms,
+                         "stream_ms_per_step": stream_ms / args.steps,
+                         "algorithmic_bytes_per_launch": bytes_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(params, batch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""Loader of libebcsim.so (the HIP kernels + C ABI).  No fallback: a missing library or a
+missing device is an error, never a silent CPU path."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libebcsim.so")
+
+_lib = None
+
+# name -> (restype, argtypes): every symbol include/ebcsim.h declares
+SYMBOLS = {
+    "ebc_abi_version": (C.c_int, []),
+    "ebc_last_error": (C.c_char_p, []),
+    "ebc_params_default": (C.c_int, [C.c_void_p]),
+    "ebc_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ebc_destroy": (C.c_int, [C.c_void_p]),
+    "ebc_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ebc_synchronize": (C.c_int, [C.c_void_p]),
+    "ebc_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ebc_set_human_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ebc_step": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ebc_lookahead": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ebc_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ebc_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "ebc_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ebc_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+
+class EbcError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libebcsim error %d: %s" % (code, message))
+        self.code = code
+
+
+def lib():
+    """dlopen libebcsim.so once; raises if it has not been built (`make -C eb-cadrl_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libebcsim.so is not built (%s). Run __graft_entry__.build() or "
+                "`make -C eb-cadrl_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+        try:
+            # torch bundles its own libamdhip64.so.7; loading it first makes this process use ONE
+            # HIP runtime whatever the import order (a second runtime sees no device)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.ebc_abi_version() != _abi.ABI_VERSION:
+            raise ImportError("libebcsim.so ABI %d != bindings %d" % (L.ebc_abi_version(), _abi.ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise EbcError(rc, lib().ebc_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,197 @@
+"""BatchedEnv — E independent scenes behind the C ABI (include/ebcsim.h).
+
+The struct-of-arrays counterpart of EntityBasedCollisionAvoidance (simulator/env.py):
+reset() uploads host-built scenes, step() is one env.step(update=True) for every env,
+lookahead() the |A|-way onestep_lookahead sweep.  Host calls take/return numpy arrays;
+the *_device calls take torch CUDA tensors and only enqueue work on the current stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, _capi
+
+
+def _np_ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class BatchedEnv:
+    def __init__(self, params, n_envs, max_humans, max_static=0, device=0):
+        self._h = C.c_void_p()
+        self.params = params
+        L = _capi.lib()
+        _capi.check(L.ebc_create(int(device), int(n_envs), int(max_humans), int(max_static),
+                                 C.addressof(params), C.byref(self._h)))
+        self._L = L
+        self.device = int(device)
+        self.E, self.N, self.S = int(n_envs), int(max_humans), int(max_static)
+        self.R = self.N + self.S
+        self.T = _abi.rot_width(params)
+        self.G = int(round(params.map_size_m / params.map_resolution))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.ebc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, scene, env_ids=None):
+        """scene: ebcsim.scene.SceneBatch padded to (max_humans, max_static)."""
+        if scene.N != self.N or scene.S != self.S:
+            raise ValueError("scene batch padded to (%d, %d), env expects (%d, %d)"
+                             % (scene.N, scene.S, self.N, self.S))
+        keep = []
+
+        def arr(a, dtype):
+            a = np.ascontiguousarray(a, dtype=dtype)
+            keep.append(a)
+            return a.ctypes.data
+
+        sc = _abi.EbcScene()
+        sc.struct_size = C.sizeof(sc)
+        sc.n = scene.n
+        sc.n_humans = arr(scene.n_humans, np.int32)
+        for k in ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref"):
+            setattr(sc, k, arr(getattr(scene, k), np.float64))
+        sc.type = arr(scene.type, np.uint8)
+        if self.S:
+            sc.n_static = arr(scene.n_static, np.int32)
+            sc.spx, sc.spy, sc.sradius = (arr(scene.spx, np.float64), arr(scene.spy, np.float64),
+                                          arr(scene.sradius, np.float64))
+        if scene.grid is not None:
+            if scene.grid.shape[1:] != (self.G, 2):
+                raise ValueError("grid must be [n][%d][2] uint64" % self.G)
+            sc.grid = arr(scene.grid, np.uint64)
+        sc.robot = arr(scene.robot, np.float64)
+        ids = None
+        if env_ids is not None:
+            ids = np.ascontiguousarray(env_ids, dtype=np.int32)
+            if len(ids) != scene.n:
+                raise ValueError("len(env_ids) != scene.n")
+        _capi.check(self._L.ebc_reset(self._h, _np_ptr(ids), C.addressof(sc)))
+
+    # ------------------------------------------------------------------ host calls
+    def set_human_actions(self, act):
+        a = np.ascontiguousarray(act, dtype=np.float64).reshape(self.E, self.N, 2)
+        _capi.check(self._L.ebc_set_human_actions(self._h, _abi.HOST, a.ctypes.data))
+
+    def step(self, robot_action=None, human_policy=_abi.HUMAN_ORCA,
+             robot_policy=_abi.ROBOT_EXTERNAL, flags=0, border=None, outputs=None):
+        E, N, R, T = self.E, self.N, self.R, self.T
+        out = dict(reward=np.zeros(E), done=np.zeros(E, np.uint8), info=np.zeros(E, np.uint8),
+                   dmin=np.zeros((E, 3)), dist_to_goal=np.zeros(E),
+                   robot_action_out=np.zeros((E, 2)), human_action=np.zeros((E, N, 2)),
+                   ob=np.zeros((E, R, 5)), obs_rotated=np.zeros((E, R, T), np.float32))
+        if outputs is not None:
+            out = {k: v for k, v in out.items() if k in outputs}
+        args = _abi.EbcStepArgs()
+        args.struct_size = C.sizeof(args)
+        args.location = _abi.HOST
+        args.human_policy, args.robot_policy = int(human_policy), int(robot_policy)
+        ra = b = None
+        if robot_action is not None:
+            ra = np.ascontiguousarray(robot_action, dtype=np.float64).reshape(E, 2)
+            args.robot_action = ra.ctypes.data
+        if border is not None:
+            b = np.ascontiguousarray(border, dtype=np.float64).reshape(4)
+            args.border = b.ctypes.data
+            flags |= _abi.FLAG_BORDER
+        args.flags = int(flags)
+        for k, v in out.items():
+            setattr(args, k, v.ctypes.data)
+        _capi.check(self._L.ebc_step(self._h, C.addressof(args)))
+        return out
+
+    def lookahead(self, actions, human_policy=_abi.HUMAN_ORCA, flags=0, border=None,
+                  want_rows=True):
+        actions = np.ascontiguousarray(actions, dtype=np.float64).reshape(-1, 2)
+        A, E, R, T = len(actions), self.E, self.R, self.T
+        out = dict(reward=np.zeros((E, A)), done=np.zeros((E, A), np.uint8),
+                   info=np.zeros((E, A), np.uint8), dmin=np.zeros((E, A, 3)),
+                   next_ob=np.zeros((E, R, 5)))
+        if want_rows:
+            out["rows_rotated"] = np.zeros((E, A, R, T), np.float32)
+        args = _abi.EbcLookaheadArgs()
+        args.struct_size = C.sizeof(args)
+        args.location = _abi.HOST
+        args.human_policy, args.n_actions = int(human_policy), A
+        args.actions = actions.ctypes.data
+        b = None
+        if border is not None:
+            b = np.ascontiguousarray(border, dtype=np.float64).reshape(4)
+            args.border = b.ctypes.data
+            flags |= _abi.FLAG_BORDER
+        args.flags = int(flags)
+        for k, v in out.items():
+            setattr(args, k, v.ctypes.data)
+        _capi.check(self._L.ebc_lookahead(self._h, C.addressof(args)))
+        return out
+
+    def get_state(self):
+        E, N = self.E, self.N
+        f = lambda *s: np.zeros(s)  # noqa: E731
+        out = dict(px=f(E, N), py=f(E, N), vx=f(E, N), vy=f(E, N), gx=f(E, N), gy=f(E, N),
+                   radius=f(E, N), v_pref=f(E, N), type=np.zeros((E, N), np.uint8),
+                   n_humans=np.zeros(E, np.int32), robot=f(E, 9), global_time=f(E),
+                   arrival_time=f(E, N), done=np.zeros(E, np.uint8))
+        v = _abi.EbcStateView()
+        v.struct_size = C.sizeof(v)
+        v.location = _abi.HOST
+        for k, a in out.items():
+            setattr(v, k, a.ctypes.data)
+        _capi.check(self._L.ebc_get_state(self._h, C.addressof(v)))
+        return out
+
+    # ------------------------------------------------------------------ device calls
+    def use_torch_stream(self):
+        """Run the kernels on torch's current CUDA(HIP) stream of this device."""
+        import torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _capi.check(self._L.ebc_set_stream(self._h, C.c_void_p(stream)))
+
+    def alloc_step_outputs(self, keys=("reward", "done", "info", "obs_rotated")):
+        """torch CUDA tensors for step_device(); the caller owns them."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        E, N, R, T = self.E, self.N, self.R, self.T
+        shapes = dict(reward=((E,), torch.float64), done=((E,), torch.uint8),
+                      info=((E,), torch.uint8), dmin=((E, 3), torch.float64),
+                      dist_to_goal=((E,), torch.float64),
+                      robot_action_out=((E, 2), torch.float64),
+                      human_action=((E, N, 2), torch.float64), ob=((E, R, 5), torch.float64),
+                      obs_rotated=((E, R, T), torch.float32))
+        return {k: torch.zeros(shapes[k][0], dtype=shapes[k][1], device=dev) for k in keys}
+
+    def step_device(self, outputs, robot_action=None, human_policy=_abi.HUMAN_ORCA,
+                    robot_policy=_abi.ROBOT_EXTERNAL, flags=0):
+        """Enqueue one step; `outputs`/`robot_action` are torch CUDA tensors (not copied)."""
+        args = _abi.EbcStepArgs()
+        args.struct_size = C.sizeof(args)
+        args.location = _abi.DEVICE
+        args.human_policy, args.robot_policy = int(human_policy), int(robot_policy)
+        args.flags = int(flags)
+        if robot_action is not None:
+            if robot_action.dtype.itemsize != 8 or robot_action.numel() != self.E * 2:
+                raise ValueError("robot_action must be float64 [E, 2]")
+            args.robot_action = robot_action.data_ptr()
+        for k, t in outputs.items():
+            setattr(args, k, t.data_ptr())
+        _capi.check(self._L.ebc_step(self._h, C.addressof(args)))
+
+    def synchronize(self):
+        _capi.check(self._L.ebc_synchronize(self._h))
+
+    def timing(self, enable=True):
+        _capi.check(self._L.ebc_timing(self._h, int(enable)))
+
+    def timing_read(self, reset=True):
+        ms, n = C.c_double(), C.c_int64()
+        _capi.check(self._L.ebc_timing_read(self._h, int(reset), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -206,7 +206,9 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static,
 int ebc_destroy(void *handle);
 
 /* Run the handle's work on an existing HIP stream (e.g. torch's current
- * stream) so the caller's events order with it.  NULL = the handle's own. */
+ * stream) so the caller's events order with it.  NULL is the HIP null stream
+ * (torch's default stream).  Until this is called the handle uses a private
+ * non-blocking stream created by ebc_create. */
 int ebc_set_stream(void *handle, void *hip_stream);
 int ebc_synchronize(void *handle);
 

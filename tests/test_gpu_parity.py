@@ -1,0 +1,267 @@
+"""GPU parity proper (-m gpu): the HIP path through the C ABI against (a) the golden vectors
+of the reference, (b) the CPU oracle on seeded random scene batches, (c) size-independent
+properties at BASELINE sizes.  Masks/codes bit-exact; float64 state 1e-9 absolute (ORCA-only
+dynamics are expected identical: no transcendental on that path); float32 rows 1e-5."""
+import configparser
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ebcsim import _abi, actions as ebc_actions, config as ebc_config, scene as ebc_scene
+from helpers import (GOLDEN, TRAJ_ORCASUB, TRAJ_PINNED, batch_from_init, check_trajectory, load,
+                     params_of)
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(params, E, N, S):
+    from ebcsim.batched import BatchedEnv
+    return BatchedEnv(params, E, N, S)
+
+
+@pytest.mark.parametrize("name", TRAJ_PINNED + TRAJ_ORCASUB)
+def test_golden_trajectories(name):
+    z = load(name)
+    b = batch_from_init(z, copies=3)
+    env = _env(params_of(z), 3, b.N, b.S)
+    env.reset(b)
+    check_trajectory(env, z, atol=1e-9)
+
+
+def test_known_answer_scenes():
+    with open(os.path.join(GOLDEN, "known_answers.json")) as f:
+        table = json.load(f)
+    for row in table:
+        cfg = configparser.RawConfigParser()
+        cfg.read_string(row["config_text"])
+        sc = ebc_scene.load_scene(ebc_scene.SceneConfig.from_config(cfg),
+                                  os.path.join(GOLDEN, "scenes", row["scene"]))
+        b = ebc_scene.SceneBatch.from_scenes([sc])
+        env = _env(ebc_config.params_from_dict(row["params"]), 1, b.N, b.S)
+        env.reset(b)
+        info = None
+        for _ in range(400):
+            out = env.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR)
+            if out["done"][0]:
+                info = int(out["info"][0])
+                break
+        assert info == row["expected_code"], (row["scene"], info)
+        z = load("known_" + row["scene"].replace(".json", "") + "_orcasub")
+        env.reset(b)
+        check_trajectory(env, z, atol=1e-9)
+
+
+def _random_batch(cfg_text, seeds, N=None, S=None):
+    cfg = configparser.RawConfigParser()
+    cfg.read_string(cfg_text)
+    sc = ebc_scene.SceneConfig.from_config(cfg)
+    scenes = [ebc_scene.generate_scene(sc, s) for s in seeds]
+    return ebc_scene.SceneBatch.from_scenes(scenes, N, S), cfg
+
+
+def _compare_step(out_g, out_o, tag, atol=1e-9):
+    np.testing.assert_array_equal(out_g["done"], out_o["done"], err_msg=tag)
+    np.testing.assert_array_equal(out_g["info"], out_o["info"], err_msg=tag)
+    for k in ("reward", "dmin", "dist_to_goal", "human_action", "ob", "robot_action_out"):
+        np.testing.assert_allclose(out_g[k], out_o[k], atol=atol, rtol=0, err_msg=tag + " " + k)
+    np.testing.assert_allclose(out_g["obs_rotated"], out_o["obs_rotated"], atol=1e-5, rtol=1e-5,
+                               err_msg=tag)
+
+
+CASES = [
+    # (fixture holding the config text, envs, steps, human policy, flags)
+    ("traj_a5_linear_orcasub", 257, 60, _abi.HUMAN_ORCA, 0),
+    ("traj_n10_walls_t17_orcasub", 130, 50, _abi.HUMAN_ORCA, 0),
+    ("traj_a3b3s2_scripted", 64, 40, _abi.HUMAN_LINEAR, 0),
+    ("traj_n10_walls_t17_orcasub", 96, 120, _abi.HUMAN_ORCA, _abi.FLAG_AUTO_RESET),
+]
+
+
+@pytest.mark.parametrize("fixture,E,steps,policy,flags", CASES)
+def test_random_batches_vs_oracle(fixture, E, steps, policy, flags):
+    """Seeded random scenes (ragged static rows), scripted robot, every output every step."""
+    from oracle import oracle
+    z = load(fixture)
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    text = _config_text(meta)
+    b, cfg = _random_batch(text, [3000 + e for e in range(E)])
+    g = _env(params, E, b.N, b.S)
+    o = oracle.OracleEnv(params, E, b.N, b.S)
+    g.reset(b)
+    o.reset(b)
+    space = ebc_actions.build_action_space(float(b.robot[0, 7]))
+    rs = np.random.RandomState(7)
+    kinds = set()
+    for t in range(steps):
+        act = space[rs.randint(len(space), size=E)]
+        og = g.step(robot_action=act, human_policy=policy, flags=flags)
+        oo = o.step(robot_action=act, human_policy=policy, flags=flags)
+        _compare_step(og, oo, "%s step %d" % (fixture, t))
+        kinds.update(og["info"].tolist())
+    sg, so = g.get_state(), o.get_state()
+    for k in sg:
+        np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
+    assert len(kinds) >= 3
+
+
+def _config_text(meta):
+    """Rebuild the INI text a trajectory fixture ran with from the scenes fixture (same config
+    file) plus the overrides recorded in its meta."""
+    zs = load("scenes")
+    for k in range(int(zs["n"])):
+        m = json.loads(str(zs["meta_%d" % k]))
+        if m["config"] == meta["config"]:
+            cfg = configparser.RawConfigParser()
+            cfg.read_string(m["config_text"])
+            for key, val in meta["overrides"].items():
+                sec, opt = key.split(".")
+                if sec in ("adults", "bicycles", "children") and opt == "policy":
+                    continue
+                cfg.set(sec, opt, str(val))
+            import io
+            buf = io.StringIO()
+            cfg.write(buf)
+            return buf.getvalue()
+    raise KeyError(meta["config"])
+
+
+def test_lookahead_vs_oracle_and_cached_step():
+    from oracle import oracle
+    z = load("traj_n10_walls_t17_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    E = 48
+    b, _ = _random_batch(_config_text(meta), [5000 + e for e in range(E)])
+    g = _env(params, E, b.N, b.S)
+    o = oracle.OracleEnv(params, E, b.N, b.S)
+    g.reset(b)
+    o.reset(b)
+    space = ebc_actions.build_action_space(float(b.robot[0, 7]))
+    rs = np.random.RandomState(9)
+    for t in range(12):
+        lg = g.lookahead(space, human_policy=_abi.HUMAN_ORCA)
+        lo = o.lookahead(space, human_policy=_abi.HUMAN_ORCA)
+        np.testing.assert_array_equal(lg["done"], lo["done"])
+        np.testing.assert_array_equal(lg["info"], lo["info"])
+        for k in ("reward", "dmin", "next_ob"):
+            np.testing.assert_allclose(lg[k], lo[k], atol=1e-9, rtol=0, err_msg=k)
+        np.testing.assert_allclose(lg["rows_rotated"], lo["rows_rotated"], atol=1e-5, rtol=1e-5)
+        act = space[rs.randint(len(space), size=E)]
+        # the real step re-uses the human velocities the look-ahead computed (ORCA once per step)
+        og = g.step(robot_action=act, human_policy=_abi.HUMAN_CACHED)
+        oo = o.step(robot_action=act, human_policy=_abi.HUMAN_ORCA)
+        _compare_step(og, oo, "cached step %d" % t)
+        # look-ahead reward of the chosen action == reward of the step (same state, same action)
+        idx = [int(np.where((space == a).all(1))[0][0]) for a in act]
+        np.testing.assert_allclose(lg["reward"][np.arange(E), idx], og["reward"], atol=1e-12)
+
+
+def test_external_human_actions_config2():
+    """BASELINE config 2: humans moved by the host (ORCA on host = the oracle here)."""
+    from oracle import oracle
+    z = load("traj_a5_linear_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    E = 200
+    b, _ = _random_batch(_config_text(meta), [7000 + e for e in range(E)])
+    g = _env(params, E, b.N, b.S)
+    o = oracle.OracleEnv(params, E, b.N, b.S)
+    g.reset(b)
+    o.reset(b)
+    for t in range(30):
+        oo = o.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR)
+        g.set_human_actions(oo["human_action"])
+        og = g.step(human_policy=_abi.HUMAN_EXTERNAL, robot_policy=_abi.ROBOT_LINEAR)
+        _compare_step(og, oo, "external step %d" % t)
+
+
+def test_partial_reset_and_ragged_humans():
+    from oracle import oracle
+    z = load("traj_a5_linear_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    E = 40
+    cfg = configparser.RawConfigParser()
+    cfg.read_string(_config_text(meta))
+    sc = ebc_scene.SceneConfig.from_config(cfg)
+    scenes = []
+    for e in range(E):
+        sc.adult_num = 1 + e % 7      # ragged: 1..7 humans, padded to 8
+        scenes.append(ebc_scene.generate_scene(sc, 9000 + e))
+    b = ebc_scene.SceneBatch.from_scenes(scenes, 8, 0)
+    g = _env(params, E, 8, 0)
+    o = oracle.OracleEnv(params, E, 8, 0)
+    g.reset(b)
+    o.reset(b)
+    for t in range(25):
+        _compare_step(g.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR),
+                      o.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR),
+                      "ragged %d" % t)
+    ids = np.array([3, 17, 4, 39], np.int32)
+    sub = ebc_scene.SceneBatch.from_scenes([scenes[i] for i in ids], 8, 0)
+    g.reset(sub, ids)
+    o.reset(sub, ids)
+    for t in range(10):
+        _compare_step(g.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR),
+                      o.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR),
+                      "after partial reset %d" % t)
+    sg, so = g.get_state(), o.get_state()
+    np.testing.assert_array_equal(sg["global_time"], so["global_time"])
+
+
+def test_full_size_properties():
+    """BASELINE sizes (4096 x 10, ORCA, walls): properties that do not need the oracle.
+    - replicas: the same 64 scenes tiled 64x give identical results in every replica;
+    - speed limit: |v_human| <= v_pref (LP2 disc), positions finite;
+    - done/info consistency; time advances by dt."""
+    z = load("traj_n10_walls_t17_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    base, _ = _random_batch(_config_text(meta), [11000 + e for e in range(64)])
+    E = 4096
+    tile = lambda a: None if a is None else np.concatenate([a] * (E // 64), axis=0)  # noqa: E731
+    b = ebc_scene.SceneBatch(E, base.N, base.S, *[tile(getattr(base, k)) for k in (
+        "n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type", "n_static",
+        "spx", "spy", "sradius", "grid", "robot")])
+    g = _env(params, E, b.N, b.S)
+    g.reset(b)
+    for t in range(40):
+        out = g.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR)
+        for k in ("reward", "info", "obs_rotated", "human_action"):
+            v = out[k].reshape(E // 64, 64, -1)
+            assert (v == v[0:1]).all() or np.allclose(v, v[0:1], equal_nan=True), (t, k)
+        speed = np.hypot(out["human_action"][..., 0], out["human_action"][..., 1])
+        # LP1 intersects float lines with the speed disc: |v| can exceed v_pref by float error
+        # (3.5e-4 seen in the oracle too), never by more
+        assert (speed <= b.v_pref * (1 + 2e-3) + 1e-3).all()
+        terminal = np.isin(out["info"], [_abi.INFO_REACH_GOAL, _abi.INFO_COLLISION_OBSTACLE,
+                                         _abi.INFO_COLLISION_ADULT, _abi.INFO_COLLISION_BICYCLE,
+                                         _abi.INFO_COLLISION_CHILD, _abi.INFO_TIMEOUT])
+        np.testing.assert_array_equal(terminal, out["done"].astype(bool))
+    st = g.get_state()
+    assert np.isfinite(st["px"]).all() and np.isfinite(st["robot"]).all()
+    np.testing.assert_allclose(st["global_time"], 40 * params.time_step, atol=1e-12)
+
+
+def test_device_resident_step_matches_host_step():
+    import torch
+    z = load("traj_a5_linear_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    E = 128
+    b, _ = _random_batch(_config_text(meta), [13000 + e for e in range(E)])
+    g1 = _env(params, E, b.N, b.S)
+    g2 = _env(params, E, b.N, b.S)
+    g1.reset(b)
+    g2.reset(b)
+    g2.use_torch_stream()
+    outs = g2.alloc_step_outputs(("reward", "done", "info", "obs_rotated", "dmin"))
+    for t in range(20):
+        h = g1.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR)
+        g2.step_device(outs, human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR)
+        torch.cuda.synchronize()
+        for k in outs:
+            np.testing.assert_array_equal(outs[k].cpu().numpy(), h[k], err_msg=k)
