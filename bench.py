@@ -45,8 +45,8 @@ def algorithmic_bytes_per_env_step(N, S, T):
     return reads + writes
 
 
-def build_batch(workload, envs, first_env):
-    from ebcsim import config as ebc_config, scene as ebc_scene
+def build_batch(workload, envs, rank):
+    from ebcsim import config as ebc_config, scene as ebc_scene, shard
     env_cfg, pol_cfg, _ = WORKLOADS[workload]
     cfg = configparser.RawConfigParser()
     cfg.read(os.path.join(PKG, "configs", env_cfg))
@@ -55,7 +55,8 @@ def build_batch(workload, envs, first_env):
     params = ebc_config.params_from_config(cfg, pol)
     sc = ebc_scene.SceneConfig.from_config(cfg)
     base = 2000 if "metric" in env_cfg else 1000
-    scenes = [ebc_scene.generate_scene(sc, base + first_env + e) for e in range(envs)]
+    start, count = shard.weak_range(envs, rank)  # weak scaling: every rank adds its own slice
+    scenes = [ebc_scene.generate_scene(sc, s) for s in shard.scene_seeds(base, start, count)]
     return params, ebc_scene.SceneBatch.from_scenes(scenes)
 
 
@@ -120,7 +121,7 @@ def main():
     from ebcsim.batched import BatchedEnv
 
     E = args.envs or WORKLOADS[args.workload][2]
-    params, batch = build_batch(args.workload, E, first_env=rank * E)
+    params, batch = build_batch(args.workload, E, rank)
     env = BatchedEnv(params, E, batch.N, batch.S, device=local_rank)
     env.reset(batch)
     env.use_torch_stream()
@@ -155,13 +156,8 @@ def main():
     kernel_ms, n_timed = env.timing_read(reset=True)
     env.timing(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    humans = torch.tensor([float(batch.n_humans.sum())], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(humans, op=dist.ReduceOp.SUM)
-    elapsed_max = float(t.item())
-    total_humans = float(humans.item())
+    from ebcsim import shard
+    elapsed_max, total_humans = shard.job_rate(elapsed, float(batch.n_humans.sum()), device=dev)
 
     if rank == 0:
         S_mean = float(batch.n_static.mean()) if batch.S else 0.0
