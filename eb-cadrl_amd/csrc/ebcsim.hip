@@ -13,11 +13,13 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "ebc_device.h"
+#include "ebc_orca_group.h"
 
 namespace {
 
@@ -360,6 +362,72 @@ __global__ __launch_bounds__(EBC_WAVE) void policy_kernel(EbcParams p, DevState 
   }
 }
 
+// ORCA with a GS-lane group per human (ebc_orca_group.h) -> s.hact.  64 / GS humans per wave;
+// lane j of a group loads "other" j of its human in ob order (env.py:396-402): the humans
+// before and after it, then the robot when it is visible.
+template <int GS>
+__global__ __launch_bounds__(EBC_WAVE) void orca_group_kernel(EbcParams p, DevState s, int auto_reset) {
+  constexpr int HPW = EBC_WAVE / GS;
+  __shared__ __align__(16) float dist_lds[EBC_WAVE];
+  __shared__ float4 lines_lds[EBC_WAVE];
+  __shared__ float4 proj_lds[EBC_WAVE];
+  const int N = s.N;
+  const int lane = threadIdx.x;
+  const int group = lane / GS;
+  const int j = lane - group * GS;
+  const long h = (long)blockIdx.x * HPW + group;
+  const bool h_ok = h < (long)s.E * N;
+  const int e = h_ok ? (int)(h / N) : 0;
+  const int i = h_ok ? (int)(h - (long)e * N) : 0;
+  const int n = h_ok ? s.n_humans[e] : 0;
+  const bool human_ok = h_ok && i < n;
+  const bool restart = h_ok && auto_reset && s.done[e];
+  const double *PX = restart ? s.px0 : s.px, *PY = restart ? s.py0 : s.py;
+  const double *VX = restart ? s.vx0 : s.vx, *VY = restart ? s.vy0 : s.vy;
+  const double *RB = (restart ? s.robot0 : s.robot) + (size_t)e * 9;
+  const size_t base = (size_t)e * N;
+
+  float posx = 0, posy = 0, velx = 0, vely = 0, radius = 0, maxSpeed = 0, prefx = 0, prefy = 0;
+  if (human_ok) {
+    const size_t k = base + i;
+    const double px = PX[k], py = PY[k];
+    posx = (float)px;
+    posy = (float)py;
+    velx = (float)VX[k];
+    vely = (float)VY[k];
+    radius = (float)(s.radius[k] + 0.01 + p.orca_safety_space);  // orca.py:116
+    maxSpeed = (float)s.v_pref[k];                                // orca.py:117
+    ebc::orca_pref_velocity(px, py, s.gx[k], s.gy[k], prefx, prefy);
+  }
+  const int n_others = human_ok ? (n - 1 + (p.robot_visible ? 1 : 0)) : 0;
+  const bool valid = j < n_others;
+  float opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
+  if (valid) {
+    if (j < n - 1) {
+      const size_t k = base + (j < i ? j : j + 1);
+      opx = (float)PX[k];
+      opy = (float)PY[k];
+      ovx = (float)VX[k];
+      ovy = (float)VY[k];
+      orad = (float)(s.radius[k] + 0.01 + p.orca_safety_space);  // orca.py:122-126
+    } else {  // the robot's observable state, last in ob (env.py:401-402)
+      opx = (float)RB[0];
+      opy = (float)RB[1];
+      ovx = (float)RB[2];
+      ovy = (float)RB[3];
+      orad = (float)(RB[4] + 0.01 + p.orca_safety_space);
+    }
+  }
+  float ox, oy;
+  ebc::orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx,
+                      opy, ovx, ovy, orad, dist_lds + group * GS, lines_lds + group * GS,
+                      proj_lds + group * GS, ox, oy);
+  if (h_ok && j == 0) {
+    s.hact[(size_t)h * 2] = human_ok ? (double)ox : 0.0;  // getAgentVelocity -> Python float
+    s.hact[(size_t)h * 2 + 1] = human_ok ? (double)oy : 0.0;
+  }
+}
+
 // Look-ahead: one wave per env.  Human velocities come from s.hact (policy_kernel ran).
 //   phase A  lanes over humans/static rows: next observable rows into LDS
 //   phase B  lanes over actions: collisions (ordered, serial over humans), grid, reward,
@@ -523,6 +591,7 @@ struct Handle {
   hipStream_t stream = nullptr;
   bool has_reset = false;
   bool has_grid = false;
+  int orca_gs = 0;  // lanes per human of the ORCA kernel; 0 = one lane per human, fused in step_kernel
   uint64_t *grid_alloc = nullptr;
   // staging for host-location calls
   void *stage = nullptr;
@@ -605,7 +674,22 @@ void launch_step_T(Handle *h, const StepIO &io, int blocks) {
     hipLaunchKernelGGL((step_kernel<POLICY, 13>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
 }
 
+int launch_orca_group(Handle *h, int auto_reset) {
+  const long humans = (long)h->s.E * h->s.N;
+  const int hpw = EBC_WAVE / h->orca_gs;
+  const int blocks = (int)((humans + hpw - 1) / hpw);
+  if (h->orca_gs == 8)
+    hipLaunchKernelGGL((orca_group_kernel<8>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, auto_reset);
+  else if (h->orca_gs == 16)
+    hipLaunchKernelGGL((orca_group_kernel<16>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, auto_reset);
+  else
+    hipLaunchKernelGGL((orca_group_kernel<32>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, auto_reset);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
 int launch_policy(Handle *h, int policy) {
+  if (policy == EBC_HUMAN_ORCA && h->orca_gs) return launch_orca_group(h, 0);
   const int epb = EBC_WAVE / h->s.N;
   const int blocks = (h->s.E + epb - 1) / epb;
   if (policy == EBC_HUMAN_ORCA)
@@ -702,6 +786,14 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
     return fail(EBC_ERR_DEVICE, "hipStreamCreate failed");
   }
   h->stream = h->own_stream;
+  {
+    // ORCA mapping: a group of 8 / 16 / 32 lanes per human when its "others" fit, else one lane
+    // per human inside step_kernel.  EBCSIM_ORCA=fused forces the latter (A/B measurements).
+    const int others = max_humans - 1 + (params->robot_visible ? 1 : 0);
+    const char *force = getenv("EBCSIM_ORCA");
+    h->orca_gs = others <= 8 ? 8 : others <= 16 ? 16 : others <= 32 ? 32 : 0;
+    if (force && strcmp(force, "fused") == 0) h->orca_gs = 0;
+  }
   *handle_out = h;
   return EBC_OK;
 }
@@ -894,7 +986,14 @@ int ebc_step(void *handle, const EbcStepArgs *a) {
     HIP_TRY(hipEventRecord(e0, h->stream));
   }
   switch (a->human_policy) {
-    case EBC_HUMAN_ORCA: launch_step_T<EBC_HUMAN_ORCA>(h, io, blocks); break;
+    case EBC_HUMAN_ORCA:
+      if (h->orca_gs) {
+        if ((rc = launch_orca_group(h, io.auto_reset)) != EBC_OK) return rc;
+        launch_step_T<EBC_HUMAN_EXTERNAL>(h, io, blocks);
+      } else {
+        launch_step_T<EBC_HUMAN_ORCA>(h, io, blocks);
+      }
+      break;
     case EBC_HUMAN_LINEAR: launch_step_T<EBC_HUMAN_LINEAR>(h, io, blocks); break;
     default: launch_step_T<EBC_HUMAN_EXTERNAL>(h, io, blocks); break;
   }

@@ -12,7 +12,9 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0].replace("void (anonymous namespace)::", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        name = name[5:] if name.startswith("void ") else name
+        name = name.split("(")[0]
         agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta[name] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size",
                                         "Scratch_Size", "VGPR_Count", "SGPR_Count")}
