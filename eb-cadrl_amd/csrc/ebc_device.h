@@ -14,7 +14,6 @@
 
 #define EBC_WAVE 64
 #define EBC_MAXNB 10       // rvo2 maxNeighbors of the reference (simulator/policy/orca.py:65)
-#define EBC_TILE_SLOTS 128 // per-wave human tile incl. one robot slot per env
 
 namespace ebc {
 
@@ -86,12 +85,19 @@ __device__ __forceinline__ int grid_collision(const uint64_t *grid, int G, doubl
       ey = ey > G ? G : ey;
       if (ey > sy) {
         // mask of columns [sy, ey) in the two 64-bit halves of a row
-        uint64_t lo = 0, hi = 0;
-        for (long y = sy; y < ey; ++y) {
-          if (y < 64) lo |= 1ull << y; else hi |= 1ull << (y - 64);
+        const int w = (int)(ey - sy);
+        const unsigned __int128 mask = (((unsigned __int128)1 << w) - 1) << sy;
+        const uint64_t lo = (uint64_t)mask, hi = (uint64_t)(mask >> 64);
+        // rows [sx, ex): the first eight are loaded together (robot radius <= 0.56 m at 0.1 m
+        // cells never needs more), the rest in a plain loop
+        uint64_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const long x = sx + r < ex ? sx + r : sx;
+          acc |= (grid[x * 2] & lo) | (grid[x * 2 + 1] & hi);
         }
-        for (long x = sx; x < ex; ++x)
-          if ((grid[x * 2] & lo) | (grid[x * 2 + 1] & hi)) collision = 1;
+        for (long x = sx + 8; x < ex; ++x) acc |= (grid[x * 2] & lo) | (grid[x * 2 + 1] & hi);
+        collision = acc != 0;
       }
     }
   }
@@ -157,213 +163,9 @@ __device__ __forceinline__ RewardOut reward_compute(const EbcParams &p, double n
   return o;
 }
 
-// ---------------------------------------------------------------------------------
-// ORCA (RVO2 v2.0 Agent.cpp / Vector2.h) in float, one lane per human.  ORCA lines
-// live in LDS, lane-interleaved: element c of line k of lane l is L[(k*4+c)*64 + l]
-// (bank = l % 32: conflict-free).  Line = {point.x, point.y, dir.x, dir.y}.
-// ---------------------------------------------------------------------------------
-#define RVO_EPS 0.00001f
-
-struct LineSet {
-  float *base;  // LDS, [EBC_MAXNB*4][64]
-  int lane;
-  __device__ __forceinline__ float get(int k, int c) const { return base[(k * 4 + c) * EBC_WAVE + lane]; }
-  __device__ __forceinline__ void set(int k, float px, float py, float dx, float dy) {
-    base[(k * 4 + 0) * EBC_WAVE + lane] = px;
-    base[(k * 4 + 1) * EBC_WAVE + lane] = py;
-    base[(k * 4 + 2) * EBC_WAVE + lane] = dx;
-    base[(k * 4 + 3) * EBC_WAVE + lane] = dy;
-  }
-};
+#define RVO_EPS 0.00001f  // RVO_EPSILON
 
 __device__ __forceinline__ float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
-
-// linearProgram1
-__device__ __forceinline__ bool lp1(const LineSet &L, int lineNo, float radius, float ovx, float ovy,
-                                    bool dirOpt, float &rx, float &ry) {
-  const float ppx = L.get(lineNo, 0), ppy = L.get(lineNo, 1);
-  const float pdx = L.get(lineNo, 2), pdy = L.get(lineNo, 3);
-  const float dotProduct = ppx * pdx + ppy * pdy;
-  const float discriminant = dotProduct * dotProduct + radius * radius - (ppx * ppx + ppy * ppy);
-  if (discriminant < 0.0f) return false;
-  const float sq = sqrtf(discriminant);
-  float tLeft = -dotProduct - sq;
-  float tRight = -dotProduct + sq;
-  for (int i = 0; i < lineNo; ++i) {
-    const float ipx = L.get(i, 0), ipy = L.get(i, 1), idx = L.get(i, 2), idy = L.get(i, 3);
-    const float denominator = det2(pdx, pdy, idx, idy);
-    const float numerator = det2(idx, idy, ppx - ipx, ppy - ipy);
-    if (fabsf(denominator) <= RVO_EPS) {
-      if (numerator < 0.0f) return false;
-      continue;
-    }
-    const float t = numerator / denominator;
-    if (denominator >= 0.0f)
-      tRight = fminf(tRight, t);
-    else
-      tLeft = fmaxf(tLeft, t);
-    if (tLeft > tRight) return false;
-  }
-  float t;
-  if (dirOpt) {
-    t = (ovx * pdx + ovy * pdy > 0.0f) ? tRight : tLeft;
-  } else {
-    t = pdx * (ovx - ppx) + pdy * (ovy - ppy);
-    t = t < tLeft ? tLeft : (t > tRight ? tRight : t);
-  }
-  rx = ppx + t * pdx;
-  ry = ppy + t * pdy;
-  return true;
-}
-
-// linearProgram2
-__device__ __forceinline__ int lp2(const LineSet &L, int n, float radius, float ovx, float ovy,
-                                   bool dirOpt, float &rx, float &ry) {
-  if (dirOpt) {
-    rx = ovx * radius;
-    ry = ovy * radius;
-  } else if (ovx * ovx + ovy * ovy > radius * radius) {
-    const float inv = 1.0f / sqrtf(ovx * ovx + ovy * ovy);  // normalize(): v * (1 / |v|)
-    rx = (ovx * inv) * radius;
-    ry = (ovy * inv) * radius;
-  } else {
-    rx = ovx;
-    ry = ovy;
-  }
-  for (int i = 0; i < n; ++i) {
-    if (det2(L.get(i, 2), L.get(i, 3), L.get(i, 0) - rx, L.get(i, 1) - ry) > 0.0f) {
-      const float tx = rx, ty = ry;
-      if (!lp1(L, i, radius, ovx, ovy, dirOpt, rx, ry)) {
-        rx = tx;
-        ry = ty;
-        return i;
-      }
-    }
-  }
-  return n;
-}
-
-// linearProgram3 (numObstLines = 0); P = projected-lines scratch in LDS
-__device__ __forceinline__ void lp3(const LineSet &L, LineSet &P, int n, int beginLine, float radius,
-                                    float &rx, float &ry) {
-  float distance = 0.0f;
-  for (int i = beginLine; i < n; ++i) {
-    const float ipx = L.get(i, 0), ipy = L.get(i, 1), idx = L.get(i, 2), idy = L.get(i, 3);
-    if (det2(idx, idy, ipx - rx, ipy - ry) > distance) {
-      int np = 0;
-      for (int j = 0; j < i; ++j) {
-        const float jpx = L.get(j, 0), jpy = L.get(j, 1), jdx = L.get(j, 2), jdy = L.get(j, 3);
-        float qx, qy;
-        const float determinant = det2(idx, idy, jdx, jdy);
-        if (fabsf(determinant) <= RVO_EPS) {
-          if (idx * jdx + idy * jdy > 0.0f) continue;
-          qx = 0.5f * (ipx + jpx);
-          qy = 0.5f * (ipy + jpy);
-        } else {
-          const float s = det2(jdx, jdy, ipx - jpx, ipy - jpy) / determinant;
-          qx = ipx + s * idx;
-          qy = ipy + s * idy;
-        }
-        const float ex = jdx - idx, ey = jdy - idy;
-        const float inv = 1.0f / sqrtf(ex * ex + ey * ey);
-        P.set(np++, qx, qy, ex * inv, ey * inv);
-      }
-      const float tx = rx, ty = ry;
-      if (lp2(P, np, radius, -idy, idx, true, rx, ry) < np) {
-        rx = tx;
-        ry = ty;
-      }
-      distance = det2(idx, idy, ipx - rx, ipy - ry);
-    }
-  }
-}
-
-// One human's ORCA velocity.  tile_* = this env's humans (and robot slot) in LDS as the
-// floats rvo2 holds: position, velocity, radius + 0.01 + safety.  Others are visited in
-// ob order (simulator/env.py:396-402): humans j != self, then the robot if visible.
-// Neighbour selection = Agent::insertAgentNeighbor: the maxNeighbors nearest within
-// neighborDist, ascending, ties by arrival -> stable rank, computed by counting.
-__device__ __forceinline__ void orca_velocity(const EbcParams &p, int self, int n_agents,
-                                              const float *tpx, const float *tpy, const float *tvx,
-                                              const float *tvy, const float *trad, float maxSpeed,
-                                              float prefx, float prefy, LineSet &L, LineSet &P,
-                                              float &out_x, float &out_y) {
-  const float posx = tpx[self], posy = tpy[self];
-  const float velx = tvx[self], vely = tvy[self];
-  const float radius = trad[self];
-  const float rangeSq = p.orca_neighbor_dist * p.orca_neighbor_dist;
-  const float invTimeHorizon = 1.0f / p.orca_time_horizon;
-  const float timeStep = (float)p.time_step;
-  const int maxN = p.orca_max_neighbors < EBC_MAXNB ? p.orca_max_neighbors : EBC_MAXNB;
-  int nn = 0;
-  for (int j = 0; j < n_agents; ++j) {
-    if (j == self) continue;
-    const float rpx = tpx[j] - posx, rpy = tpy[j] - posy;      // relativePosition
-    const float ddx = posx - tpx[j], ddy = posy - tpy[j];      // position_ - other (insertAgentNeighbor)
-    const float distSqN = ddx * ddx + ddy * ddy;
-    if (!(distSqN < rangeSq)) continue;
-    int rank = 0;
-    for (int k = 0; k < n_agents; ++k) {
-      if (k == self || k == j) continue;
-      const float ex = posx - tpx[k], ey = posy - tpy[k];
-      const float dk = ex * ex + ey * ey;
-      rank += (dk < distSqN || (dk == distSqN && k < j)) ? 1 : 0;
-    }
-    if (rank >= maxN) continue;
-    ++nn;
-    // Agent::computeNewVelocity, one ORCA line
-    const float rvx = velx - tvx[j], rvy = vely - tvy[j];       // relativeVelocity
-    const float distSq = rpx * rpx + rpy * rpy;
-    const float combinedRadius = radius + trad[j];
-    const float combinedRadiusSq = combinedRadius * combinedRadius;
-    float dirx, diry, ux, uy;
-    if (distSq > combinedRadiusSq) {
-      const float wx = rvx - invTimeHorizon * rpx, wy = rvy - invTimeHorizon * rpy;
-      const float wLengthSq = wx * wx + wy * wy;
-      const float dotProduct1 = wx * rpx + wy * rpy;
-      if (dotProduct1 < 0.0f && dotProduct1 * dotProduct1 > combinedRadiusSq * wLengthSq) {
-        const float wLength = sqrtf(wLengthSq);
-        const float inv = 1.0f / wLength;
-        const float unx = wx * inv, uny = wy * inv;
-        dirx = uny;
-        diry = -unx;
-        const float s = combinedRadius * invTimeHorizon - wLength;
-        ux = s * unx;
-        uy = s * uny;
-      } else {
-        const float leg = sqrtf(distSq - combinedRadiusSq);
-        const float inv = 1.0f / distSq;
-        if (det2(rpx, rpy, wx, wy) > 0.0f) {
-          dirx = (rpx * leg - rpy * combinedRadius) * inv;
-          diry = (rpx * combinedRadius + rpy * leg) * inv;
-        } else {
-          dirx = -((rpx * leg + rpy * combinedRadius) * inv);
-          diry = -((-rpx * combinedRadius + rpy * leg) * inv);
-        }
-        const float dotProduct2 = rvx * dirx + rvy * diry;
-        ux = dotProduct2 * dirx - rvx;
-        uy = dotProduct2 * diry - rvy;
-      }
-    } else {
-      const float invTimeStep = 1.0f / timeStep;
-      const float wx = rvx - invTimeStep * rpx, wy = rvy - invTimeStep * rpy;
-      const float wLength = sqrtf(wx * wx + wy * wy);
-      const float inv = 1.0f / wLength;
-      const float unx = wx * inv, uny = wy * inv;
-      dirx = uny;
-      diry = -unx;
-      const float s = combinedRadius * invTimeStep - wLength;
-      ux = s * unx;
-      uy = s * uny;
-    }
-    L.set(rank, velx + 0.5f * ux, vely + 0.5f * uy, dirx, diry);
-  }
-  float rx, ry;
-  const int lineFail = lp2(L, nn, maxSpeed, prefx, prefy, false, rx, ry);
-  if (lineFail < nn) lp3(L, P, nn, lineFail, maxSpeed, rx, ry);
-  out_x = rx;
-  out_y = ry;
-}
 
 // ORCA.predict's Python-side preferred velocity (simulator/policy/orca.py:136-140)
 __device__ __forceinline__ void orca_pref_velocity(double px, double py, double gx, double gy,

@@ -1,14 +1,5 @@
-// ebcsim.hip — kernels and C ABI of libebcsim.so (gfx950 / MI355X).
-//
-// Kernels
-//   step_kernel<POLICY, T>      one env.step(update=True) for every env
-//                                (simulator/env.py:388-466), one lane per human,
-//                                one wave per workgroup, floor(64 / N) envs per wave.
-//   policy_kernel<POLICY>       human velocities only (feeds look-ahead and CACHED steps)
-//   lookahead_kernel<T>         the |A|-way onestep_lookahead sweep
-//                                (rl/policy/multi_human_rl.py:38-61), one wave per env.
-// Layout in HBM: struct-of-arrays doubles [E][N] per human field (lane = e*N + i, so a
-// wave's loads are contiguous), robot [E][9], grid [E][G][2] 64-bit words.
+// ebcsim.hip — C ABI of libebcsim.so (gfx950 / MI355X): handle, device buffers, launches.
+// Kernels: ebc_kernels.h; device arithmetic: ebc_device.h, ebc_orca_group.h.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -16,555 +7,16 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
-#include "ebc_device.h"
-#include "ebc_orca_group.h"
+#include "ebc_kernels.h"
 
 namespace {
 
-struct DevState {
-  int E, N, S, G;
-  int *n_humans;
-  double *px, *py, *vx, *vy, *gx, *gy, *radius, *v_pref;
-  uint8_t *type;
-  int *n_static;
-  double *spx, *spy, *sradius;
-  uint64_t *grid;  // nullptr when every map is free
-  double *robot;
-  double *time;
-  double *arrival;
-  uint8_t *done;
-  double *hact;  // [E][N][2]
-  double *px0, *py0, *vx0, *vy0, *robot0;
-};
-
-struct StepIO {
-  const double *robot_action;
-  double border[4];
-  int has_border;
-  int robot_policy;
-  int auto_reset;
-  double *reward;
-  uint8_t *done;
-  uint8_t *info;
-  double *dmin;
-  double *dist_to_goal;
-  double *robot_action_out;
-  double *human_action;
-  double *ob;
-  float *obs_rotated;
-};
-
-struct LookIO {
-  const double *actions;
-  int A;
-  double border[4];
-  int has_border;
-  double *reward;
-  uint8_t *done;
-  uint8_t *info;
-  double *dmin;
-  double *next_ob;
-  float *rows;
-};
-
-// Human velocity for lane `i` of env-slot `el`.  The per-wave LDS tile holds, for each
-// env of the wave, N human slots followed by one robot slot (stride N + 1).
-template <int POLICY>
-__device__ __forceinline__ void human_policy(const EbcParams &p, const DevState &s, bool active,
-                                             int e, int i, int n, int tile_base, double px, double py,
-                                             double gx, double gy, double v_pref, const float *tpx,
-                                             const float *tpy, const float *tvx, const float *tvy,
-                                             const float *trad, ebc::LineSet &L, ebc::LineSet &P,
-                                             double &ax, double &ay) {
-  ax = 0;
-  ay = 0;
-  if (!active) return;
-  if (POLICY == EBC_HUMAN_EXTERNAL || POLICY == EBC_HUMAN_CACHED) {
-    ax = s.hact[((size_t)e * s.N + i) * 2];
-    ay = s.hact[((size_t)e * s.N + i) * 2 + 1];
-  } else if (POLICY == EBC_HUMAN_LINEAR) {
-    ebc::linear_policy(px, py, gx, gy, v_pref, ax, ay);
-  } else {
-    float prefx, prefy, ox, oy;
-    ebc::orca_pref_velocity(px, py, gx, gy, prefx, prefy);
-    // others in ob order: humans 0..n-1 (self skipped) then the robot slot (index n) if visible.
-    // The robot slot sits at tile index N; when n < N it is addressed through a remap below.
-    const int n_agents = n + (p.robot_visible ? 1 : 0);
-    ebc::orca_velocity(p, i, n_agents, tpx + tile_base, tpy + tile_base, tvx + tile_base,
-                       tvy + tile_base, trad + tile_base, (float)v_pref, prefx, prefy, L, P, ox, oy);
-    ax = (double)ox;  // getAgentVelocity -> Python float
-    ay = (double)oy;
-  }
-}
-
-template <int POLICY, int T>
-__global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p, DevState s, StepIO io) {
-  __shared__ float tpx[EBC_TILE_SLOTS], tpy[EBC_TILE_SLOTS], tvx[EBC_TILE_SLOTS],
-      tvy[EBC_TILE_SLOTS], trad[EBC_TILE_SLOTS];
-  __shared__ double sh_d[EBC_WAVE];
-  __shared__ double sh_ract[EBC_WAVE][2];
-  __shared__ double sh_robot[EBC_WAVE][9];
-  __shared__ float lines[POLICY == EBC_HUMAN_ORCA ? EBC_MAXNB * 4 * EBC_WAVE : 1];
-  __shared__ float plines[POLICY == EBC_HUMAN_ORCA ? EBC_MAXNB * 4 * EBC_WAVE : 1];
-
-  const int N = s.N, S = s.S, R = N + S;
-  const int lane = threadIdx.x;
-  const int epb = EBC_WAVE / N;  // envs per wave
-  const int el = lane / N;
-  const int i = lane - el * N;
-  const int e = blockIdx.x * epb + el;
-  const bool env_ok = el < epb && e < s.E;
-  const int n = env_ok ? s.n_humans[e] : 0;
-  const bool active = env_ok && i < n;
-  const bool leader = env_ok && i == 0;
-  const size_t k = (size_t)(env_ok ? e : 0) * N + i;
-  const double dt = p.time_step;
-
-  const bool restart = env_ok && io.auto_reset && s.done[e];
-  const double *rb_in = (restart ? s.robot0 : s.robot) + (size_t)(env_ok ? e : 0) * 9;
-  double rb[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) rb[c] = env_ok ? rb_in[c] : 0.0;
-  const double gtime = (env_ok && !restart) ? s.time[e] : 0.0;
-
-  double px = 0, py = 0, vx = 0, vy = 0, gx = 0, gy = 0, rad = 0, vpref = 0, arrival = 0;
-  int type = 0;
-  if (active) {
-    px = restart ? s.px0[k] : s.px[k];
-    py = restart ? s.py0[k] : s.py[k];
-    vx = restart ? s.vx0[k] : s.vx[k];
-    vy = restart ? s.vy0[k] : s.vy[k];
-    gx = s.gx[k];
-    gy = s.gy[k];
-    rad = s.radius[k];
-    vpref = s.v_pref[k];
-    type = s.type[k];
-    arrival = restart ? 0.0 : s.arrival[k];
-  }
-
-  // --- stage the wave's envs in LDS as the floats rvo2 holds (orca.py:110-133)
-  const int tile_base = el * (N + 1);
-  if (POLICY == EBC_HUMAN_ORCA) {
-    if (active) {
-      tpx[tile_base + i] = (float)px;
-      tpy[tile_base + i] = (float)py;
-      tvx[tile_base + i] = (float)vx;
-      tvy[tile_base + i] = (float)vy;
-      trad[tile_base + i] = (float)(rad + 0.01 + p.orca_safety_space);
-    }
-    if (leader) {  // robot as the last "other" (env.py:401-402): slot n
-      tpx[tile_base + n] = (float)rb[0];
-      tpy[tile_base + n] = (float)rb[1];
-      tvx[tile_base + n] = (float)rb[2];
-      tvy[tile_base + n] = (float)rb[3];
-      trad[tile_base + n] = (float)(rb[4] + 0.01 + p.orca_safety_space);
-    }
-  }
-  // --- robot action (leader), shared through LDS
-  if (leader) {
-    double a0, a1;
-    if (io.robot_policy == EBC_ROBOT_LINEAR) {
-      ebc::linear_policy(rb[0], rb[1], rb[5], rb[6], rb[7], a0, a1);
-    } else {
-      a0 = io.robot_action[2 * (size_t)e];
-      a1 = io.robot_action[2 * (size_t)e + 1];
-    }
-    sh_ract[el][0] = a0;
-    sh_ract[el][1] = a1;
-  }
-  __syncthreads();
-
-  // --- humans choose their velocity on the pre-step state (env.py:393-405)
-  ebc::LineSet L{lines, lane}, P{plines, lane};
-  double ax, ay;
-  human_policy<POLICY>(p, s, active, e, i, n, tile_base, px, py, gx, gy, vpref, tpx, tpy, tvx, tvy,
-                       trad, L, P, ax, ay);
-
-  // --- swept robot-human distance with the humans' CURRENT velocity (collisions.py:35-42)
-  const double a0 = sh_ract[env_ok ? el : 0][0], a1 = sh_ract[env_ok ? el : 0][1];
-  double rvx, rvy;
-  if (p.robot_kinematics == EBC_HOLONOMIC) {
-    rvx = a0;
-    rvy = a1;
-  } else {
-    rvx = a0 * cos(a1 + rb[8]);
-    rvy = a0 * sin(a1 + rb[8]);
-  }
-  sh_d[lane] = active ? ebc::closest_dist(px, py, vx, vy, rad, rb[0], rb[1], rb[4], rvx, rvy, dt) : 0.0;
-  // type rides along in the tile of the next phase: reuse tvx slot? keep it simple: own array
-  __shared__ uint8_t sh_type[EBC_WAVE];
-  sh_type[lane] = (uint8_t)type;
-  __syncthreads();
-
-  // --- leader: ordered per-type reduction with break at first hit (env.py:303-338),
-  //     grid window, reward, robot update
-  if (leader) {
-    double dmin[3] = {INFINITY, INFINITY, INFINITY};
-    int coll[4] = {0, 0, 0, 0};
-    for (int j = 0; j < n; ++j) {
-      const int t = sh_type[lane + j];
-      const double d = sh_d[lane + j];
-      if (t < 3 && !coll[t]) {
-        if (d < 0)
-          coll[t] = 1;
-        else if (d < dmin[t])
-          dmin[t] = d;
-      }
-    }
-    double nx, ny;
-    ebc::robot_next_position(rb, p.robot_kinematics, a0, a1, dt, nx, ny);
-    coll[3] = ebc::grid_collision(s.grid ? s.grid + (size_t)e * s.G * 2 : nullptr, s.G, p.map_size_m,
-                                  p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
-    const ebc::RewardOut ro = ebc::reward_compute(p, nx, ny, rb[5], rb[6], rb[4], a1, gtime, dmin, coll);
-    // Agent.step for the robot (agent.py:202-228)
-    rb[0] = nx;
-    rb[1] = ny;
-    if (p.robot_kinematics == EBC_HOLONOMIC) {
-      rb[2] = a0;
-      rb[3] = a1;
-    } else {
-      rb[8] = ebc::py_mod(rb[8] + a1, 2 * M_PI);
-      rb[2] = a0 * cos(rb[8]);
-      rb[3] = a0 * sin(rb[8]);
-    }
-    double *rb_out = s.robot + (size_t)e * 9;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) {
-      rb_out[c] = rb[c];
-      sh_robot[el][c] = rb[c];
-    }
-    s.time[e] = gtime + dt;
-    s.done[e] = (uint8_t)ro.done;
-    if (io.reward) io.reward[e] = ro.reward;
-    if (io.done) io.done[e] = (uint8_t)ro.done;
-    if (io.info) io.info[e] = (uint8_t)ro.info;
-    if (io.dmin) {
-      io.dmin[3 * (size_t)e] = dmin[0];
-      io.dmin[3 * (size_t)e + 1] = dmin[1];
-      io.dmin[3 * (size_t)e + 2] = dmin[2];
-    }
-    if (io.dist_to_goal) io.dist_to_goal[e] = ro.dist_to_goal;
-    if (io.robot_action_out) {
-      io.robot_action_out[2 * (size_t)e] = a0;
-      io.robot_action_out[2 * (size_t)e + 1] = a1;
-    }
-  }
-  __syncthreads();
-
-  // --- humans move (agent.py:202-211), first-arrival times (env.py:365-378)
-  if (active) {
-    px = px + ax * dt;
-    py = py + ay * dt;
-    vx = ax;
-    vy = ay;
-    const double tnew = gtime + dt;
-    if (arrival == 0 && ebc::norm2(px - gx, py - gy) < rad) arrival = tnew;
-    s.px[k] = px;
-    s.py[k] = py;
-    s.vx[k] = vx;
-    s.vy[k] = vy;
-    s.arrival[k] = arrival;
-  }
-  if (env_ok && io.human_action) {
-    io.human_action[k * 2] = active ? ax : 0.0;
-    io.human_action[k * 2 + 1] = active ? ay : 0.0;
-  }
-
-  // --- returned observation: humans then static rows (env.py:381-382, :457-458), raw and
-  //     rotated into the robot frame (cadrl.py:236-337)
-  if (env_ok && (io.ob || io.obs_rotated)) {
-    const int ns = S ? s.n_static[e] : 0;
-    const ebc::RotFrame f = ebc::rot_frame(sh_robot[el], p.rotate_unicycle);
-    for (int r = i; r < R; r += N) {
-      double opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
-      int otype = 0;
-      bool valid = false;
-      if (r < n) {  // r == i: this lane's own human
-        opx = px; opy = py; ovx = vx; ovy = vy; orad = rad; otype = type;
-        valid = true;
-      } else if (r - n < ns) {
-        const size_t q = (size_t)e * S + (r - n);
-        opx = s.spx[q]; opy = s.spy[q]; orad = s.sradius[q]; otype = EBC_ADULT_STATIC;
-        valid = true;
-      }
-      const size_t row = (size_t)e * R + r;
-      if (io.ob) {
-        double *o = io.ob + row * 5;
-        o[0] = opx; o[1] = opy; o[2] = ovx; o[3] = ovy; o[4] = orad;
-      }
-      if (io.obs_rotated) {
-        float out[T];
-        if (valid) {
-          ebc::rotate_row<T>(f, opx, opy, ovx, ovy, orad, otype, out);
-        } else {
-#pragma unroll
-          for (int c = 0; c < T; ++c) out[c] = 0.0f;
-        }
-        float *o = io.obs_rotated + row * T;
-#pragma unroll
-        for (int c = 0; c < T; ++c) o[c] = out[c];
-      }
-    }
-  }
-}
-
-// Human velocities only -> s.hact (look-ahead, CACHED steps).  Same mapping as step_kernel.
-template <int POLICY>
-__global__ __launch_bounds__(EBC_WAVE) void policy_kernel(EbcParams p, DevState s) {
-  __shared__ float tpx[EBC_TILE_SLOTS], tpy[EBC_TILE_SLOTS], tvx[EBC_TILE_SLOTS],
-      tvy[EBC_TILE_SLOTS], trad[EBC_TILE_SLOTS];
-  __shared__ float lines[POLICY == EBC_HUMAN_ORCA ? EBC_MAXNB * 4 * EBC_WAVE : 1];
-  __shared__ float plines[POLICY == EBC_HUMAN_ORCA ? EBC_MAXNB * 4 * EBC_WAVE : 1];
-  const int N = s.N;
-  const int lane = threadIdx.x;
-  const int epb = EBC_WAVE / N;
-  const int el = lane / N;
-  const int i = lane - el * N;
-  const int e = blockIdx.x * epb + el;
-  const bool env_ok = el < epb && e < s.E;
-  const int n = env_ok ? s.n_humans[e] : 0;
-  const bool active = env_ok && i < n;
-  const size_t k = (size_t)(env_ok ? e : 0) * N + i;
-  double px = 0, py = 0, gx = 0, gy = 0, vpref = 0;
-  const int tile_base = el * (N + 1);
-  if (active) {
-    px = s.px[k];
-    py = s.py[k];
-    gx = s.gx[k];
-    gy = s.gy[k];
-    vpref = s.v_pref[k];
-    if (POLICY == EBC_HUMAN_ORCA) {
-      tpx[tile_base + i] = (float)px;
-      tpy[tile_base + i] = (float)py;
-      tvx[tile_base + i] = (float)s.vx[k];
-      tvy[tile_base + i] = (float)s.vy[k];
-      trad[tile_base + i] = (float)(s.radius[k] + 0.01 + p.orca_safety_space);
-    }
-  }
-  if (POLICY == EBC_HUMAN_ORCA && env_ok && i == 0) {
-    const double *rb = s.robot + (size_t)e * 9;
-    tpx[tile_base + n] = (float)rb[0];
-    tpy[tile_base + n] = (float)rb[1];
-    tvx[tile_base + n] = (float)rb[2];
-    tvy[tile_base + n] = (float)rb[3];
-    trad[tile_base + n] = (float)(rb[4] + 0.01 + p.orca_safety_space);
-  }
-  __syncthreads();
-  ebc::LineSet L{lines, lane}, P{plines, lane};
-  double ax, ay;
-  human_policy<POLICY>(p, s, active, e, i, n, tile_base, px, py, gx, gy, vpref, tpx, tpy, tvx, tvy,
-                       trad, L, P, ax, ay);
-  if (env_ok) {
-    s.hact[k * 2] = active ? ax : 0.0;
-    s.hact[k * 2 + 1] = active ? ay : 0.0;
-  }
-}
-
-// ORCA with a GS-lane group per human (ebc_orca_group.h) -> s.hact.  64 / GS humans per wave;
-// lane j of a group loads "other" j of its human in ob order (env.py:396-402): the humans
-// before and after it, then the robot when it is visible.
-template <int GS>
-__global__ __launch_bounds__(EBC_WAVE) void orca_group_kernel(EbcParams p, DevState s, int auto_reset) {
-  constexpr int HPW = EBC_WAVE / GS;
-  __shared__ __align__(16) float dist_lds[EBC_WAVE];
-  __shared__ float4 lines_lds[EBC_WAVE];
-  __shared__ float4 proj_lds[EBC_WAVE];
-  const int N = s.N;
-  const int lane = threadIdx.x;
-  const int group = lane / GS;
-  const int j = lane - group * GS;
-  const long h = (long)blockIdx.x * HPW + group;
-  const bool h_ok = h < (long)s.E * N;
-  const int e = h_ok ? (int)(h / N) : 0;
-  const int i = h_ok ? (int)(h - (long)e * N) : 0;
-  const int n = h_ok ? s.n_humans[e] : 0;
-  const bool human_ok = h_ok && i < n;
-  const bool restart = h_ok && auto_reset && s.done[e];
-  const double *PX = restart ? s.px0 : s.px, *PY = restart ? s.py0 : s.py;
-  const double *VX = restart ? s.vx0 : s.vx, *VY = restart ? s.vy0 : s.vy;
-  const double *RB = (restart ? s.robot0 : s.robot) + (size_t)e * 9;
-  const size_t base = (size_t)e * N;
-
-  float posx = 0, posy = 0, velx = 0, vely = 0, radius = 0, maxSpeed = 0, prefx = 0, prefy = 0;
-  if (human_ok) {
-    const size_t k = base + i;
-    const double px = PX[k], py = PY[k];
-    posx = (float)px;
-    posy = (float)py;
-    velx = (float)VX[k];
-    vely = (float)VY[k];
-    radius = (float)(s.radius[k] + 0.01 + p.orca_safety_space);  // orca.py:116
-    maxSpeed = (float)s.v_pref[k];                                // orca.py:117
-    ebc::orca_pref_velocity(px, py, s.gx[k], s.gy[k], prefx, prefy);
-  }
-  const int n_others = human_ok ? (n - 1 + (p.robot_visible ? 1 : 0)) : 0;
-  const bool valid = j < n_others;
-  float opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
-  if (valid) {
-    if (j < n - 1) {
-      const size_t k = base + (j < i ? j : j + 1);
-      opx = (float)PX[k];
-      opy = (float)PY[k];
-      ovx = (float)VX[k];
-      ovy = (float)VY[k];
-      orad = (float)(s.radius[k] + 0.01 + p.orca_safety_space);  // orca.py:122-126
-    } else {  // the robot's observable state, last in ob (env.py:401-402)
-      opx = (float)RB[0];
-      opy = (float)RB[1];
-      ovx = (float)RB[2];
-      ovy = (float)RB[3];
-      orad = (float)(RB[4] + 0.01 + p.orca_safety_space);
-    }
-  }
-  float ox, oy;
-  ebc::orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx,
-                      opy, ovx, ovy, orad, dist_lds + group * GS, lines_lds + group * GS,
-                      proj_lds + group * GS, ox, oy);
-  if (h_ok && j == 0) {
-    s.hact[(size_t)h * 2] = human_ok ? (double)ox : 0.0;  // getAgentVelocity -> Python float
-    s.hact[(size_t)h * 2 + 1] = human_ok ? (double)oy : 0.0;
-  }
-}
-
-// Look-ahead: one wave per env.  Human velocities come from s.hact (policy_kernel ran).
-//   phase A  lanes over humans/static rows: next observable rows into LDS
-//   phase B  lanes over actions: collisions (ordered, serial over humans), grid, reward,
-//            and the robot-frame terms of rotate() for that action
-//   phase C  lanes over (action, row): rotated rows
-#define EBC_LA_MAX_ROWS 128
-#define EBC_LA_MAX_ACTIONS 128
-template <int T>
-__global__ __launch_bounds__(EBC_WAVE) void lookahead_kernel(EbcParams p, DevState s, LookIO io) {
-  __shared__ double hpx[EBC_WAVE], hpy[EBC_WAVE], hvx[EBC_WAVE], hvy[EBC_WAVE], hrad[EBC_WAVE];
-  __shared__ uint8_t htype[EBC_WAVE];
-  __shared__ double row[EBC_LA_MAX_ROWS][5];
-  __shared__ uint8_t row_type[EBC_LA_MAX_ROWS];
-  __shared__ ebc::RotFrame frames[EBC_LA_MAX_ACTIONS];
-  const int N = s.N, S = s.S, R = N + S, A = io.A;
-  const int lane = threadIdx.x;
-  const int e = blockIdx.x;
-  const int n = s.n_humans[e];
-  const int ns = S ? s.n_static[e] : 0;
-  const double dt = p.time_step;
-  const double *rbp = s.robot + (size_t)e * 9;
-  double rb[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) rb[c] = rbp[c];
-
-  // phase A: get_next_observable_state (agent.py:80-93), static rows appended (env.py:457-458)
-  for (int r = lane; r < R; r += EBC_WAVE) {
-    double o[5] = {0, 0, 0, 0, 0};
-    int t = 0;
-    if (r < n) {
-      const size_t k = (size_t)e * N + r;
-      const double ax = s.hact[k * 2], ay = s.hact[k * 2 + 1];
-      hpx[r] = s.px[k]; hpy[r] = s.py[k]; hvx[r] = s.vx[k]; hvy[r] = s.vy[k];
-      hrad[r] = s.radius[k]; htype[r] = s.type[k];
-      o[0] = hpx[r] + ax * dt;
-      o[1] = hpy[r] + ay * dt;
-      o[2] = ax;
-      o[3] = ay;
-      o[4] = hrad[r];
-      t = htype[r];
-    } else if (r - n < ns) {
-      const size_t q = (size_t)e * S + (r - n);
-      o[0] = s.spx[q]; o[1] = s.spy[q]; o[4] = s.sradius[q];
-      t = EBC_ADULT_STATIC;
-    }
-#pragma unroll
-    for (int c = 0; c < 5; ++c) row[r][c] = o[c];
-    row_type[r] = (uint8_t)t;
-    if (io.next_ob) {
-      double *dst = io.next_ob + ((size_t)e * R + r) * 5;
-#pragma unroll
-      for (int c = 0; c < 5; ++c) dst[c] = o[c];
-    }
-  }
-  __syncthreads();
-
-  // phase B
-  const double gtime = s.time[e];
-  for (int a = lane; a < A; a += EBC_WAVE) {
-    const double a0 = io.actions[2 * a], a1 = io.actions[2 * a + 1];
-    double rvx, rvy;
-    if (p.robot_kinematics == EBC_HOLONOMIC) {
-      rvx = a0;
-      rvy = a1;
-    } else {
-      rvx = a0 * cos(a1 + rb[8]);
-      rvy = a0 * sin(a1 + rb[8]);
-    }
-    double dmin[3] = {INFINITY, INFINITY, INFINITY};
-    int coll[4] = {0, 0, 0, 0};
-    for (int j = 0; j < n; ++j) {
-      const int t = htype[j];
-      if (t < 3 && !coll[t]) {
-        const double d = ebc::closest_dist(hpx[j], hpy[j], hvx[j], hvy[j], hrad[j], rb[0], rb[1],
-                                           rb[4], rvx, rvy, dt);
-        if (d < 0)
-          coll[t] = 1;
-        else if (d < dmin[t])
-          dmin[t] = d;
-      }
-    }
-    double nx, ny;
-    ebc::robot_next_position(rb, p.robot_kinematics, a0, a1, dt, nx, ny);
-    coll[3] = ebc::grid_collision(s.grid ? s.grid + (size_t)e * s.G * 2 : nullptr, s.G, p.map_size_m,
-                                  p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
-    const ebc::RewardOut ro = ebc::reward_compute(p, nx, ny, rb[5], rb[6], rb[4], a1, gtime, dmin, coll);
-    const size_t o = (size_t)e * A + a;
-    if (io.reward) io.reward[o] = ro.reward;
-    if (io.done) io.done[o] = (uint8_t)ro.done;
-    if (io.info) io.info[o] = (uint8_t)ro.info;
-    if (io.dmin) {
-      io.dmin[3 * o] = dmin[0];
-      io.dmin[3 * o + 1] = dmin[1];
-      io.dmin[3 * o + 2] = dmin[2];
-    }
-    if (io.rows) {
-      // CADRL.propagate for the robot (cadrl.py:118-165)
-      double nb[9];
-#pragma unroll
-      for (int c = 0; c < 9; ++c) nb[c] = rb[c];
-      if (p.robot_kinematics == EBC_HOLONOMIC) {
-        nb[0] = rb[0] + a0 * dt;
-        nb[1] = rb[1] + a1 * dt;
-        nb[2] = a0;
-        nb[3] = a1;
-      } else {
-        const double nth = rb[8] + a1;
-        const double nvx = a0 * cos(nth), nvy = a0 * sin(nth);
-        nb[0] = rb[0] + nvx * dt;
-        nb[1] = rb[1] + nvy * dt;
-        nb[2] = nvx;
-        nb[3] = nvy;
-        nb[8] = nth;
-      }
-      frames[a] = ebc::rot_frame(nb, p.rotate_unicycle);
-    }
-  }
-  if (!io.rows) return;
-  __syncthreads();
-
-  // phase C: rows_rotated[e][a][r][:]
-  const int total = A * R;
-  for (int idx = lane; idx < total; idx += EBC_WAVE) {
-    const int a = idx / R, r = idx - a * R;
-    float out[T];
-    if (r < n + ns) {
-      ebc::rotate_row<T>(frames[a], row[r][0], row[r][1], row[r][2], row[r][3], row[r][4],
-                         row_type[r], out);
-    } else {
-#pragma unroll
-      for (int c = 0; c < T; ++c) out[c] = 0.0f;
-    }
-    float *dst = io.rows + ((size_t)e * A * R + idx) * T;
-#pragma unroll
-    for (int c = 0; c < T; ++c) dst[c] = out[c];
-  }
-}
+using ebc::DevState;
+using ebc::LookIO;
+using ebc::StepIO;
 
 // ------------------------------------------------------------------------------ host
 thread_local std::string g_err;
@@ -591,7 +43,7 @@ struct Handle {
   hipStream_t stream = nullptr;
   bool has_reset = false;
   bool has_grid = false;
-  int orca_gs = 0;  // lanes per human of the ORCA kernel; 0 = one lane per human, fused in step_kernel
+  int orca_gs = 16;  // lanes per human of the ORCA role (8 / 16 / 32 / 64)
   uint64_t *grid_alloc = nullptr;
   // staging for host-location calls
   void *stage = nullptr;
@@ -666,36 +118,49 @@ int check_handle(void *handle, Handle **out) {
   return EBC_OK;
 }
 
-template <int POLICY>
-void launch_step_T(Handle *h, const StepIO &io, int blocks) {
-  if (h->T == 17)
-    hipLaunchKernelGGL((step_kernel<POLICY, 17>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
-  else
-    hipLaunchKernelGGL((step_kernel<POLICY, 13>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+int human_blocks(const Handle *h) {
+  const int epb = EBC_WAVE / h->s.N;
+  return (h->s.E + epb - 1) / epb;
 }
 
-int launch_orca_group(Handle *h, int auto_reset) {
+int orca_blocks(const Handle *h) {
   const long humans = (long)h->s.E * h->s.N;
   const int hpw = EBC_WAVE / h->orca_gs;
-  const int blocks = (int)((humans + hpw - 1) / hpw);
-  if (h->orca_gs == 8)
-    hipLaunchKernelGGL((orca_group_kernel<8>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, auto_reset);
-  else if (h->orca_gs == 16)
-    hipLaunchKernelGGL((orca_group_kernel<16>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, auto_reset);
-  else
-    hipLaunchKernelGGL((orca_group_kernel<32>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, auto_reset);
+  return (int)((humans + hpw - 1) / hpw);
+}
+
+// phase 1: ENV role on `env_blocks` workgroups, ORCA role on `orca` more
+int launch_phase1(Handle *h, const StepIO &io, int env_blocks, int orca) {
+  const int blocks = env_blocks + orca;
+  if (blocks == 0) return EBC_OK;
+#define P1_(GS) hipLaunchKernelGGL((ebc::phase1_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, env_blocks)
+  switch (h->orca_gs) {
+    case 8: P1_(8); break;
+    case 16: P1_(16); break;
+    default: P1_(32); break;
+  }
+#undef P1_
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
 
-int launch_policy(Handle *h, int policy) {
-  if (policy == EBC_HUMAN_ORCA && h->orca_gs) return launch_orca_group(h, 0);
-  const int epb = EBC_WAVE / h->s.N;
-  const int blocks = (h->s.E + epb - 1) / epb;
-  if (policy == EBC_HUMAN_ORCA)
-    hipLaunchKernelGGL((policy_kernel<EBC_HUMAN_ORCA>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s);
-  else if (policy == EBC_HUMAN_LINEAR)
-    hipLaunchKernelGGL((policy_kernel<EBC_HUMAN_LINEAR>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s);
+template <int POLICY>
+int launch_phase2(Handle *h, const StepIO &io) {
+  const int blocks = human_blocks(h);
+  if (h->T == 17)
+    hipLaunchKernelGGL((ebc::phase2_kernel<POLICY, 17>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+  else
+    hipLaunchKernelGGL((ebc::phase2_kernel<POLICY, 13>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+template <int POLICY>
+int launch_lookahead(Handle *h, const LookIO &io) {
+  if (h->T == 17)
+    hipLaunchKernelGGL((ebc::lookahead_kernel<POLICY, 17>), dim3(h->s.E), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+  else
+    hipLaunchKernelGGL((ebc::lookahead_kernel<POLICY, 13>), dim3(h->s.E), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
@@ -738,8 +203,8 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   if (params->struct_size != sizeof(EbcParams))
     return fail(EBC_ERR_INVALID, "EbcParams.struct_size does not match this library");
   if (n_envs <= 0 || max_humans <= 0 || max_static < 0) return fail(EBC_ERR_INVALID, "bad dimensions");
-  if (max_humans > EBC_WAVE - 1)
-    return fail(EBC_ERR_UNSUPPORTED, "max_humans > 63 (one wave per scene group)");
+  if (max_humans - 1 + (params->robot_visible ? 1 : 0) > 32)
+    return fail(EBC_ERR_UNSUPPORTED, "more than 32 other agents per human (ORCA group of 32 lanes)");
   if (max_humans + max_static > EBC_LA_MAX_ROWS)
     return fail(EBC_ERR_UNSUPPORTED, "max_humans + max_static > 128 observation rows");
   if (params->orca_max_neighbors > EBC_MAXNB || params->orca_max_neighbors < 0)
@@ -769,7 +234,9 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
 #define A_(field, cnt) if (rc == EBC_OK) rc = dev_alloc(h, &s.field, (cnt))
   A_(n_humans, n_envs); A_(px, EN); A_(py, EN); A_(vx, EN); A_(vy, EN); A_(gx, EN); A_(gy, EN);
   A_(radius, EN); A_(v_pref, EN); A_(type, EN); A_(n_static, n_envs); A_(spx, ES); A_(spy, ES);
-  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN);
+  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs);
+  A_(time_n, n_envs); A_(arrival, EN); A_(fpx, EN); A_(fpy, EN); A_(fvx, EN); A_(fvy, EN); A_(frad, EN);
+  A_(fmax, EN); A_(fprefx, EN); A_(fprefy, EN);
   A_(done, n_envs); A_(hact, EN * 2); A_(px0, EN); A_(py0, EN); A_(vx0, EN); A_(vy0, EN);
   A_(robot0, (size_t)n_envs * 9);
 #undef A_
@@ -787,12 +254,9 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   }
   h->stream = h->own_stream;
   {
-    // ORCA mapping: a group of 8 / 16 / 32 lanes per human when its "others" fit, else one lane
-    // per human inside step_kernel.  EBCSIM_ORCA=fused forces the latter (A/B measurements).
+    // ORCA role: the smallest group of 8 / 16 / 32 / 64 lanes that holds a human's "others"
     const int others = max_humans - 1 + (params->robot_visible ? 1 : 0);
-    const char *force = getenv("EBCSIM_ORCA");
-    h->orca_gs = others <= 8 ? 8 : others <= 16 ? 16 : others <= 32 ? 32 : 0;
-    if (force && strcmp(force, "fused") == 0) h->orca_gs = 0;
+    h->orca_gs = others <= 8 ? 8 : others <= 16 ? 16 : 32;
   }
   *handle_out = h;
   return EBC_OK;
@@ -911,6 +375,12 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *sc) {
     HIP_TRY(hipMemset(s.done + e, 0, (size_t)cnt));
     if (contiguous) break;
   }
+  {  // the float tile the ORCA role reads (orca.py:110-140), for the whole batch
+    const size_t EN = (size_t)s.E * N;
+    hipLaunchKernelGGL(ebc::tile_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0, h->stream, h->p, h->s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   h->has_reset = true;
   return EBC_OK;
 }
@@ -970,8 +440,6 @@ int ebc_step(void *handle, const EbcStepArgs *a) {
     io.human_action = st.out(a->human_action, E * N * 2); io.ob = st.out(a->ob, E * R * 5);
     io.obs_rotated = st.out(a->obs_rotated, E * R * T);
   }
-  const int epb = EBC_WAVE / s.N;
-  const int blocks = (s.E + epb - 1) / epb;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->timing) {
     if (h->ev_used + 2 > h->ev.size()) {
@@ -985,19 +453,14 @@ int ebc_step(void *handle, const EbcStepArgs *a) {
     e1 = h->ev[h->ev_used++];
     HIP_TRY(hipEventRecord(e0, h->stream));
   }
-  switch (a->human_policy) {
-    case EBC_HUMAN_ORCA:
-      if (h->orca_gs) {
-        if ((rc = launch_orca_group(h, io.auto_reset)) != EBC_OK) return rc;
-        launch_step_T<EBC_HUMAN_EXTERNAL>(h, io, blocks);
-      } else {
-        launch_step_T<EBC_HUMAN_ORCA>(h, io, blocks);
-      }
-      break;
-    case EBC_HUMAN_LINEAR: launch_step_T<EBC_HUMAN_LINEAR>(h, io, blocks); break;
-    default: launch_step_T<EBC_HUMAN_EXTERNAL>(h, io, blocks); break;
-  }
-  HIP_TRY(hipGetLastError());
+  const bool orca = a->human_policy == EBC_HUMAN_ORCA;
+  if ((rc = launch_phase1(h, io, human_blocks(h), orca ? orca_blocks(h) : 0)) != EBC_OK) return rc;
+  rc = a->human_policy == EBC_HUMAN_LINEAR ? launch_phase2<EBC_HUMAN_LINEAR>(h, io)
+                                           : launch_phase2<EBC_HUMAN_EXTERNAL>(h, io);
+  if (rc != EBC_OK) return rc;
+  // the "next" robot / time buffers become current
+  std::swap(h->s.robot, h->s.robot_n);
+  std::swap(h->s.time, h->s.time_n);
   if (h->timing) HIP_TRY(hipEventRecord(e1, h->stream));
   if (a->location != EBC_DEVICE) return st.finish();
   return EBC_OK;
@@ -1037,13 +500,14 @@ int ebc_lookahead(void *handle, const EbcLookaheadArgs *a) {
     io.info = st.out(a->info, E * A); io.dmin = st.out(a->dmin, E * A * 3);
     io.next_ob = st.out(a->next_ob, E * R * 5); io.rows = st.out(a->rows_rotated, E * A * R * T);
   }
-  if (a->human_policy == EBC_HUMAN_ORCA || a->human_policy == EBC_HUMAN_LINEAR)
-    if ((rc = launch_policy(h, a->human_policy)) != EBC_OK) return rc;
-  if (h->T == 17)
-    hipLaunchKernelGGL((lookahead_kernel<17>), dim3(s.E), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
-  else
-    hipLaunchKernelGGL((lookahead_kernel<13>), dim3(s.E), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
-  HIP_TRY(hipGetLastError());
+  if (a->human_policy == EBC_HUMAN_ORCA) {  // ORCA role only -> hact
+    StepIO none;
+    memset(&none, 0, sizeof(none));
+    if ((rc = launch_phase1(h, none, 0, orca_blocks(h))) != EBC_OK) return rc;
+  }
+  rc = a->human_policy == EBC_HUMAN_LINEAR ? launch_lookahead<EBC_HUMAN_LINEAR>(h, io)
+                                           : launch_lookahead<EBC_HUMAN_EXTERNAL>(h, io);
+  if (rc != EBC_OK) return rc;
   if (a->location != EBC_DEVICE) return st.finish();
   return EBC_OK;
 }

@@ -86,7 +86,8 @@ enum {
 
 /* flags */
 enum {
-  EBC_FLAG_AUTO_RESET = 1, /* an env whose previous step was terminal restarts from its reset() scene */
+  EBC_FLAG_AUTO_RESET = 1, /* a terminal step's outputs describe the terminal transition; the env's
+                              state is then put back to its reset() scene (time 0) for the next step */
   EBC_FLAG_BORDER = 2      /* border[4] valid: simulator/env.py:264-271 */
 };
 
