@@ -1,0 +1,176 @@
+"""The single-env object facade (ebcsim.env) against the reference's own scenario tests and the
+golden trajectories.  On CPU the facade is driven with the oracle injected as backend (the
+object plumbing is what is under test); with -m gpu the same scenarios run on the HIP library."""
+import configparser
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ebcsim import _abi
+from ebcsim import env as ebc_env
+from ebcsim import info as ebc_info
+from ebcsim.action import ActionRot, ActionXY
+from ebcsim.agents import Robot
+from ebcsim.policy import policy_factory
+from ebcsim.state import FullState, JointState, ObservableState
+from helpers import GOLDEN, load
+
+
+def _oracle_backend(params, E, N, S):
+    from oracle import oracle
+    return oracle.OracleEnv(params, E, N, S)
+
+
+def _make(cfg_text, backend, kinematics=None):
+    cfg = configparser.RawConfigParser()
+    cfg.read_string(cfg_text)
+    env = ebc_env.make(backend_factory=backend)
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    env.set_robot(robot)
+    pol = policy_factory["linear"]()
+    robot.set_policy(pol)
+    if kinematics:
+        pol.kinematics = robot.kinematics = kinematics
+    pol.set_phase("test")
+    return env, robot
+
+
+def _known_answers(backend):
+    """tests/test_collisions_simulation.py:35-69 of the reference, call for call."""
+    with open(os.path.join(GOLDEN, "known_answers.json")) as f:
+        table = json.load(f)
+    for row in table:
+        env, robot = _make(row["config_text"], backend)
+        ob, local_map = env.reset("test", load_scene_path=os.path.join(GOLDEN, "scenes", row["scene"]))
+        done = False
+        steps = 0
+        while not done:
+            action = robot.act(ob, local_map=local_map, env=env)
+            ob, _, reward, done, info = env.step(action)
+            steps += 1
+            assert steps < 500
+        assert isinstance(info, getattr(ebc_info, row["expected"])), (row["scene"], str(info))
+        assert len(env.states) == steps and isinstance(env.states[0][0], FullState)
+
+
+def _golden_trajectory(name, backend):
+    z = load(name)
+    meta = json.loads(str(z["meta"]))
+    zs = load("scenes")
+    text = None
+    for k in range(int(zs["n"])):
+        m = json.loads(str(zs["meta_%d" % k]))
+        if m["config"] == meta["config"]:
+            cfg = configparser.RawConfigParser()
+            cfg.read_string(m["config_text"])
+            for key, val in meta["overrides"].items():
+                sec, opt = key.split(".")
+                if not cfg.has_section(sec):
+                    cfg.add_section(sec)
+                cfg.set(sec, opt, str(val))
+            if meta["human_policy"] != "linear":
+                for sec in ("adults", "bicycles", "children"):
+                    if cfg.has_section(sec):
+                        cfg.set(sec, "policy", "orca")
+            import io
+            buf = io.StringIO()
+            cfg.write(buf)
+            text = buf.getvalue()
+            break
+    kin = None if meta["kinematics"] == "holonomic" else meta["kinematics"]
+    env, robot = _make(text, backend, kin)
+    ob, _ = env.reset("test", test_case=meta["seed_case"])
+    n = len(z["init_px"])
+    np.testing.assert_array_equal([o.px for o in ob[:n]], z["init_px"])
+    la_steps = list(z["la_step"]) if "la_step" in z.files else []
+    for t in range(len(z["action"])):
+        a = z["action"][t]
+        action = ActionXY(*a) if kin is None else ActionRot(*a)
+        if t in la_steps:
+            k = la_steps.index(t)
+            for ai in (0, 7, 40, 80):
+                la = z["la_actions"][ai]
+                cand = ActionXY(*la) if kin is None else ActionRot(*la)
+                nob, r, d, inf = env.onestep_lookahead(cand)
+                assert d == bool(z["la_done"][k][ai])
+                np.testing.assert_allclose(r, z["la_reward"][k][ai], atol=1e-9)
+                np.testing.assert_allclose([[o.px, o.py, o.vx, o.vy, o.radius] for o in nob],
+                                           z["la_next_ob"][k][:, :5], atol=1e-9)
+        ob, local_map, reward, done, info = env.step(action)
+        assert local_map is None
+        assert done == bool(z["done"][t]), t
+        assert type(info).__name__ == ["Nothing", "Danger", "ReachGoal", "CollisionObstacle",
+                                       "CollisionAdult", "CollisionBicycle", "CollisionChild",
+                                       "Timeout"][int(z["info"][t])]
+        np.testing.assert_allclose(reward, z["reward"][t], atol=1e-9)
+        rows = np.array([[o.px, o.py, o.vx, o.vy, o.radius, int(o.obj_type)] for o in ob])
+        np.testing.assert_allclose(rows, z["ob"][t], atol=1e-9)
+        assert all(isinstance(o, ObservableState) for o in ob)
+        if not np.isnan(z["min_dist"][t]):
+            np.testing.assert_allclose(info.min_dist, z["min_dist"][t], atol=1e-9)
+        np.testing.assert_allclose(env.global_time, z["time"][t], atol=1e-12)
+        np.testing.assert_allclose([robot.px, robot.py, robot.vx, robot.vy, robot.theta],
+                                   z["robot"][t][[0, 1, 2, 3, 8]], atol=1e-9)
+        times = list(env.adult_times) + list(env.bicycle_times) + list(env.children_times)
+        np.testing.assert_allclose(times, z["arrival"][t], atol=1e-12)
+    # JointState of the robot and the returned ob is what rotate() consumes
+    js = JointState(robot.get_full_state(), ob)
+    assert len(js.self_state + js.agent_states[0]) == 15
+
+
+def test_value_objects_concatenate_like_the_reference():
+    f = FullState(1, 2, 3, 4, 5, 6, 7, 8, 9, 4)
+    o = ObservableState(10, 11, 12, 13, 14, 2)
+    assert f + o == (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 2)
+    assert f.position == (1, 2) and f.goal_position == (6, 7) and o.velocity == (12, 13)
+    assert str(ebc_info.ReachGoal()) == "Reaching goal" and str(ebc_info.Nothing()) == ""
+    assert str(ebc_info.Danger(0.1)) == "Too close" and str(ebc_info.Timeout()) == "Timeout"
+
+
+def test_simulator_module_paths_resolve():
+    from simulator.utils.info import ReachGoal, CollisionAdult  # noqa: F401
+    from simulator.utils.action import ActionXY as A  # noqa: F401
+    from simulator.utils.state import JointState as J  # noqa: F401
+    from simulator.agents.robot import Robot as R  # noqa: F401
+    from simulator.policy.policy_factory import policy_factory as pf
+    from simulator.env import EntityBasedCollisionAvoidance as E  # noqa: F401
+    assert "linear" in pf and ReachGoal is ebc_info.ReachGoal
+
+
+def test_reset_errors_like_the_reference():
+    z = json.load(open(os.path.join(GOLDEN, "known_answers.json")))[0]
+    cfg = configparser.RawConfigParser()
+    cfg.read_string(z["config_text"])
+    env = ebc_env.make(backend_factory=_oracle_backend)
+    env.configure(cfg)
+    with pytest.raises(AttributeError):
+        env.reset("test")
+    env.set_robot(Robot(cfg, "robot"))
+    with pytest.raises(AssertionError):
+        env.reset("bogus")
+
+
+def test_known_answer_scenes_cpu_backend():
+    _known_answers(_oracle_backend)
+
+
+@pytest.mark.parametrize("name", ["traj_a5_scripted", "traj_a3b3s2_scripted_orcasub",
+                                  "traj_unicycle_rotpen", "traj_n10_walls_t17_orcasub"])
+def test_golden_trajectory_cpu_backend(name):
+    _golden_trajectory(name, _oracle_backend)
+
+
+@pytest.mark.gpu
+def test_known_answer_scenes_gpu():
+    _known_answers(None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["traj_a5_scripted", "traj_a3b3s2_scripted_orcasub",
+                                  "traj_unicycle_rotpen", "traj_n10_walls_t17_orcasub",
+                                  "traj_a5_linear_orcasub"])
+def test_golden_trajectory_gpu(name):
+    _golden_trajectory(name, None)
