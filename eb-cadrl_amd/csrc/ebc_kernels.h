@@ -1,28 +1,21 @@
 // ebc_kernels.h — the HIP kernels of libebcsim.so (gfx950 / MI355X).
 //
-// One env.step (simulator/env.py:388-466) is two launches:
-//
-//   phase1_kernel<GS>   heterogeneous grid.  Workgroups [0, env_blocks) take the ENV role,
-//                       the rest the ORCA role; both read only pre-step state, so they run
-//                       side by side and the robot-side serial work (one lane per env) hides
-//                       behind the ORCA waves.
-//       ENV role   lane = human, floor(64 / N) envs per wave.  Robot action, swept
-//                  robot-human distance with the humans' CURRENT velocity
-//                  (collisions.py:35-42), ordered per-type reduction (env.py:303-313), grid
-//                  window (env.py:227-271), reward / done / info (reward.py:80-181), robot
-//                  update (agent.py:202-228) into the "next" robot/time buffers.
-//       ORCA role  GS lanes per human (ebc_orca_group.h) over the float tile the previous
-//                  phase 2 (or reset) left in HBM -> hact.
-//   phase2_kernel<POLICY, T>  lane = human.  Humans move (agent.py:202-211), first-arrival
-//                  times (env.py:365-378), returned observation raw and rotated
-//                  (env.py:381-382, :457-458; cadrl.py:236-337), auto-reset, and the float
-//                  tile of the state the NEXT step will see (the casts rvo2 makes,
-//                  orca.py:110-140, fused into the producer).
-//
+// One env.step (simulator/env.py:388-466) = robot-side "service" work (lane per human: robot
+// action, collisions, reward, then human update + observation) plus the humans' ORCA velocities
+// (GS lanes per human, ebc_orca_group.h, over the float tile the previous step left in HBM).
+//   phase1_kernel<GS> + phase2_kernel<T>   ORCA humans, two launches: a heterogeneous grid of
+//                              one-wave workgroups (service_env waves at full lane use beside
+//                              ORCA waves; both read only pre-step state), then service_commit.
+//   step_kernel<POLICY,T>      humans on the linear policy or with supplied / cached velocities:
+//                              one launch, service_env + service_commit in the same wave.
+// (A fused single-launch ORCA step -- service wave + ORCA waves per workgroup with an LDS
+// hand-off -- was built and measured: never faster than the split form on MI355X once the
+// service chain was cut down, and 1.6x slower at 4096 x 10; see DESIGN.md.)
+//   orca_kernel<GS>     ORCA alone -> hact (look-ahead prelude)
 //   lookahead_kernel<T> the |A|-way onestep_lookahead sweep (multi_human_rl.py:38-61).
 //
 // HBM layout: struct-of-arrays [E][N] per human field (lane = e*N + i -> contiguous wave
-// accesses), robot [E][9] and time [E] double-buffered (cur / next), grid [E][G][2] u64.
+// accesses), robot [E][9], time [E], grid [E][G][2] u64.
 #pragma once
 
 #include "ebc_device.h"
@@ -38,8 +31,9 @@ struct DevState {
   int *n_static;
   double *spx, *spy, *sradius;
   uint64_t *grid;  // nullptr when every map is free
-  double *robot, *robot_n;  // current / next [E][9]
-  double *time, *time_n;    // current / next [E]
+  double *robot;    // [E][9] FullState order
+  double *robot_n;  // [E][9] scratch: next robot state between phase 1 and phase 2
+  double *time;   // [E] global_time
   double *arrival;
   uint8_t *done;  // terminal flag of the last step
   double *hact;   // [E][N][2] human velocities: ORCA role, ebc_set_human_actions, or look-ahead cache
@@ -79,27 +73,6 @@ struct LookIO {
   float *rows;
 };
 
-// lane -> (env, human) of the lane-per-human mapping
-struct HumanLane {
-  int el, i, e, n;
-  bool env_ok, active, leader;
-  size_t k;
-};
-__device__ __forceinline__ HumanLane human_lane(const DevState &s, int block) {
-  HumanLane m;
-  const int N = s.N, lane = threadIdx.x;
-  const int epb = EBC_WAVE / N;
-  m.el = lane / N;
-  m.i = lane - m.el * N;
-  m.e = block * epb + m.el;
-  m.env_ok = m.el < epb && m.e < s.E;
-  m.n = m.env_ok ? s.n_humans[m.e] : 0;
-  m.active = m.env_ok && m.i < m.n;
-  m.leader = m.env_ok && m.i == 0;
-  m.k = (size_t)(m.env_ok ? m.e : 0) * N + m.i;
-  return m;
-}
-
 // The float tile entry of one human (orca.py:110-140): written by reset and by phase 2.
 __device__ __forceinline__ void store_tile(const EbcParams &p, const DevState &s, size_t k, double px,
                                            double py, double vx, double vy, double gx, double gy,
@@ -122,125 +95,24 @@ __global__ __launch_bounds__(256) void tile_kernel(EbcParams p, DevState s) {
   store_tile(p, s, k, s.px[k], s.py[k], s.vx[k], s.vy[k], s.gx[k], s.gy[k], s.radius[k], s.v_pref[k]);
 }
 
-// ------------------------------------------------------------------------- ENV role
-__device__ __forceinline__ void env_role(const EbcParams &p, const DevState &s, const StepIO &io,
-                                         int block) {
-  __shared__ double sh_d[EBC_WAVE];
-  __shared__ double sh_ract[EBC_WAVE][2];
-  __shared__ uint8_t sh_type[EBC_WAVE];
-  const HumanLane m = human_lane(s, block);
-  const int lane = threadIdx.x;
-  const double dt = p.time_step;
-  const double *rb_in = s.robot + (size_t)(m.env_ok ? m.e : 0) * 9;
-  double rb[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) rb[c] = m.env_ok ? rb_in[c] : 0.0;
-  const double gtime = m.env_ok ? s.time[m.e] : 0.0;
-  double px = 0, py = 0, vx = 0, vy = 0, rad = 0;
-  int type = 0;
-  if (m.active) {
-    px = s.px[m.k];
-    py = s.py[m.k];
-    vx = s.vx[m.k];
-    vy = s.vy[m.k];
-    rad = s.radius[m.k];
-    type = s.type[m.k];
-  }
-  if (m.leader) {
-    double a0, a1;
-    if (io.robot_policy == EBC_ROBOT_LINEAR) {
-      linear_policy(rb[0], rb[1], rb[5], rb[6], rb[7], a0, a1);
-    } else {
-      a0 = io.robot_action[2 * (size_t)m.e];
-      a1 = io.robot_action[2 * (size_t)m.e + 1];
-    }
-    sh_ract[m.el][0] = a0;
-    sh_ract[m.el][1] = a1;
-  }
-  __syncthreads();
-  const double a0 = sh_ract[m.env_ok ? m.el : 0][0], a1 = sh_ract[m.env_ok ? m.el : 0][1];
-  double rvx, rvy;
-  if (p.robot_kinematics == EBC_HOLONOMIC) {
-    rvx = a0;
-    rvy = a1;
-  } else {
-    rvx = a0 * cos(a1 + rb[8]);
-    rvy = a0 * sin(a1 + rb[8]);
-  }
-  sh_d[lane] = m.active ? closest_dist(px, py, vx, vy, rad, rb[0], rb[1], rb[4], rvx, rvy, dt) : 0.0;
-  sh_type[lane] = (uint8_t)type;
-  __syncthreads();
-  if (!m.leader) return;
-
-  // ordered per-type reduction with break at the first hit (env.py:303-313)
-  double dm0 = INFINITY, dm1 = INFINITY, dm2 = INFINITY;
-  int c0 = 0, c1 = 0, c2 = 0;
-  for (int j = 0; j < m.n; ++j) {
-    const int t = sh_type[lane + j];
-    const double d = sh_d[lane + j];
-    const bool hit = d < 0;
-    if (t == 0 && !c0) { c0 = hit; dm0 = (!hit && d < dm0) ? d : dm0; }
-    if (t == 1 && !c1) { c1 = hit; dm1 = (!hit && d < dm1) ? d : dm1; }
-    if (t == 2 && !c2) { c2 = hit; dm2 = (!hit && d < dm2) ? d : dm2; }
-  }
-  const double dmin[3] = {dm0, dm1, dm2};
-  double nx, ny;
-  robot_next_position(rb, p.robot_kinematics, a0, a1, dt, nx, ny);
-  int coll[4] = {c0, c1, c2, 0};
-  coll[3] = grid_collision(s.grid ? s.grid + (size_t)m.e * s.G * 2 : nullptr, s.G, p.map_size_m,
-                           p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
-  const RewardOut ro = reward_compute(p, nx, ny, rb[5], rb[6], rb[4], a1, gtime, dmin, coll);
-  // Agent.step for the robot (agent.py:202-228)
-  rb[0] = nx;
-  rb[1] = ny;
-  if (p.robot_kinematics == EBC_HOLONOMIC) {
-    rb[2] = a0;
-    rb[3] = a1;
-  } else {
-    rb[8] = py_mod(rb[8] + a1, 2 * M_PI);
-    rb[2] = a0 * cos(rb[8]);
-    rb[3] = a0 * sin(rb[8]);
-  }
-  double *rb_out = s.robot_n + (size_t)m.e * 9;
-#pragma unroll
-  for (int c = 0; c < 9; ++c) rb_out[c] = rb[c];
-  s.time_n[m.e] = gtime + dt;
-  s.done[m.e] = (uint8_t)ro.done;
-  const size_t e = (size_t)m.e;
-  if (io.reward) io.reward[e] = ro.reward;
-  if (io.done) io.done[e] = (uint8_t)ro.done;
-  if (io.info) io.info[e] = (uint8_t)ro.info;
-  if (io.dmin) {
-    io.dmin[3 * e] = dm0;
-    io.dmin[3 * e + 1] = dm1;
-    io.dmin[3 * e + 2] = dm2;
-  }
-  if (io.dist_to_goal) io.dist_to_goal[e] = ro.dist_to_goal;
-  if (io.robot_action_out) {
-    io.robot_action_out[2 * e] = a0;
-    io.robot_action_out[2 * e + 1] = a1;
-  }
-}
-
-// ------------------------------------------------------------------------- ORCA role
-// 64 / GS humans per wave; lane j of a group loads "other" j of its human in ob order
+// ------------------------------------------------------------------------- ORCA wave
+// One wave = 64 / GS humans; lane j of a group loads "other" j of its human in ob order
 // (env.py:396-402): the humans before and after it, then the robot when it is visible.
+// `scratch` = this wave's private LDS (EBC_ORCA_LDS bytes).  Returns the group's velocity in
+// every lane of the group.
+#define EBC_ORCA_LDS (EBC_WAVE * 4 + 2 * EBC_WAVE * 16)
 template <int GS>
-__device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s, int block) {
-  constexpr int HPW = EBC_WAVE / GS;
-  __shared__ __align__(16) float dist_lds[EBC_WAVE];
-  __shared__ float4 lines_lds[EBC_WAVE];
-  __shared__ float4 proj_lds[EBC_WAVE];
+__device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s, bool h_ok, int e, int i,
+                                          unsigned char *scratch, float &ox, float &oy, bool &human_ok) {
+  float *dist_lds = reinterpret_cast<float *>(scratch);
+  float4 *lines_lds = reinterpret_cast<float4 *>(scratch + EBC_WAVE * 4);
+  float4 *proj_lds = lines_lds + EBC_WAVE;
   const int N = s.N;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (EBC_WAVE - 1);
   const int group = lane / GS;
   const int j = lane - group * GS;
-  const long h = (long)block * HPW + group;
-  const bool h_ok = h < (long)s.E * N;
-  const int e = h_ok ? (int)(h / N) : 0;
-  const int i = h_ok ? (int)(h - (long)e * N) : 0;
   const int n = h_ok ? s.n_humans[e] : 0;
-  const bool human_ok = h_ok && i < n;
+  human_ok = h_ok && i < n;
   const size_t base = (size_t)e * N;
   // tile loads do not wait for n_humans: indices are clamped into the env's row, validity is
   // decided afterwards (padded slots hold zeros)
@@ -274,91 +146,311 @@ __device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s,
     ovy = (float)rb[3];
     orad = (float)(rb[4] + 0.01 + p.orca_safety_space);
   }
-  float ox, oy;
   orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy,
                  ovx, ovy, orad, dist_lds + group * GS, lines_lds + group * GS, proj_lds + group * GS,
                  ox, oy);
+}
+
+// ORCA alone -> s.hact: the prelude of a look-ahead sweep (the following step re-uses it).
+template <int GS>
+__global__ __launch_bounds__(EBC_WAVE) void orca_kernel(EbcParams p, DevState s) {
+  constexpr int HPW = EBC_WAVE / GS;
+  __shared__ __align__(16) unsigned char scratch[EBC_ORCA_LDS];
+  const int group = threadIdx.x / GS, j = threadIdx.x - group * GS;
+  const long h = (long)blockIdx.x * HPW + group;
+  const bool h_ok = h < (long)s.E * s.N;
+  const int e = h_ok ? (int)(h / s.N) : 0;
+  const int i = h_ok ? (int)(h - (long)e * s.N) : 0;
+  float ox, oy;
+  bool human_ok;
+  orca_wave<GS>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
   if (h_ok && j == 0) {
     s.hact[(size_t)h * 2] = human_ok ? (double)ox : 0.0;  // getAgentVelocity -> Python float
     s.hact[(size_t)h * 2 + 1] = human_ok ? (double)oy : 0.0;
   }
 }
 
-template <int GS>
-__global__ __launch_bounds__(EBC_WAVE) void phase1_kernel(EbcParams p, DevState s, StepIO io,
-                                                          int env_blocks) {
-  if ((int)blockIdx.x < env_blocks)
-    env_role(p, s, io, blockIdx.x);
-  else
-    orca_role<GS>(p, s, blockIdx.x - env_blocks);
+// ------------------------------------------------------------------------- step
+// The "service" work of a step, lane = human slot (floor(64 / N) envs per wave):
+//   service_env     robot action, swept robot-human distance with the humans' CURRENT velocity
+//                   (collisions.py:35-42), ordered per-type reduction (env.py:303-313), grid
+//                   window (env.py:227-271), reward / done / info (reward.py:80-181), robot
+//                   update (agent.py:202-228).  Pre-step state only.
+//   service_commit  humans move (agent.py:202-211), first arrivals (env.py:365-378), returned
+//                   observation raw and rotated (env.py:381-382, :457-458; cadrl.py:236-337),
+//                   auto-reset, and the float tile of the state the NEXT step will see (the
+//                   casts rvo2 makes, orca.py:110-140, fused into the producer).
+// An empty asm that "uses and redefines" a value: the compiler must have the value ready HERE, so
+// the s_waitcnt for a load lands at this point (before the step's first store: vector memory
+// operations retire in issue order and a wait placed behind stores waits for them too), and an
+// address computed from kernel arguments is materialised in VGPRs here instead of re-reading the
+// kernarg segment (s_load + lgkmcnt(0)) in the middle of the dependent chain.
+template <typename Tp>
+__device__ __forceinline__ void pin(Tp &x) {
+  asm volatile("" : "+v"(x));
 }
 
-// ------------------------------------------------------------------------- phase 2
-template <int POLICY, int T>
-__global__ __launch_bounds__(EBC_WAVE) void phase2_kernel(EbcParams p, DevState s, StepIO io) {
-  const HumanLane m = human_lane(s, blockIdx.x);
+// The kernel-argument block lives in (device) memory that is not cached like ordinary data: every
+// s_load of it that the compiler places in the middle of the service wave's dependent chain is a
+// memory round trip (the argument structs are ~700 B, far more than the SGPR file keeps live, so
+// the compiler re-reads them ~30 times).  The service wave therefore copies the block into LDS
+// once, with a few wave-wide vector loads, and reads fields from LDS afterwards.
+struct ArgBlock {
+  EbcParams p;
+  DevState s;
+  StepIO io;
+};
+template <typename Tp>
+__device__ __forceinline__ void stage_args(Tp *dst_lds, const Tp &src, int lane) {
+  const uint32_t *from = reinterpret_cast<const uint32_t *>(&src);
+  uint32_t *to = reinterpret_cast<uint32_t *>(dst_lds);
+  for (int w = lane; w < (int)(sizeof(Tp) / 4); w += EBC_WAVE) to[w] = from[w];
+}
+
+struct LaneMap {
+  int el, i, n, ns;
+  size_t ee, k;
+  bool env_ok, active, leader;
+};
+struct HumanRegs {
+  double px, py, vx, vy, gx, gy, rad, vpref, arrival;
+  int type;
+};
+
+__device__ __forceinline__ LaneMap lane_map(const DevState &s, int e0, int epb, int lane) {
+  LaneMap m;
+  const int N = s.N;
+  m.el = lane / N;
+  m.i = lane - m.el * N;
+  const int e = e0 + m.el;
+  m.env_ok = m.el < epb && e < s.E;
+  m.ee = m.env_ok ? (size_t)e : 0;
+  m.k = m.ee * N + m.i;
+  m.n = m.env_ok ? s.n_humans[m.ee] : 0;
+  m.ns = (m.env_ok && s.S) ? s.n_static[m.ee] : 0;
+  m.active = m.env_ok && m.i < m.n;
+  m.leader = m.env_ok && m.i == 0;
+  return m;
+}
+
+__device__ __forceinline__ HumanRegs load_human(const DevState &s, const LaneMap &m) {
+  HumanRegs h = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (m.env_ok) {  // padded slots hold zeros; `active` decides what is used
+    h.px = s.px[m.k];
+    h.py = s.py[m.k];
+    h.vx = s.vx[m.k];
+    h.vy = s.vy[m.k];
+    h.gx = s.gx[m.k];
+    h.gy = s.gy[m.k];
+    h.rad = s.radius[m.k];
+    h.vpref = s.v_pref[m.k];
+    h.type = s.type[m.k];
+    h.arrival = s.arrival[m.k];
+  }
+  return h;  // the callers pin() these after issuing every other load
+}
+
+// Everything service_commit reads from HBM, loaded BEFORE the first store of the step: vector
+// memory operations retire in issue order, so a load issued behind stores waits for them
+// (the profile of the first fused kernel showed 73 % of the service wave's cycles in s_waitcnt).
+#define EBC_MAXT 4  // observation rows per lane that are preloaded (R <= 4 N); more fall back to late loads
+struct CommitPre {
+  double px0, py0, vx0, vy0;  // reset() scene of this human (auto-reset)
+  double r0[9];               // reset() robot (leader lanes)
+  double sx[EBC_MAXT], sy[EBC_MAXT], sr[EBC_MAXT];  // static rows this lane will emit
+};
+
+__device__ __forceinline__ CommitPre preload_commit(const DevState &s, const StepIO &io, const LaneMap &m) {
+  CommitPre c;
+  c.px0 = c.py0 = c.vx0 = c.vy0 = 0;
+  if (io.auto_reset && m.env_ok) {
+    c.px0 = s.px0[m.k];
+    c.py0 = s.py0[m.k];
+    c.vx0 = s.vx0[m.k];
+    c.vy0 = s.vy0[m.k];
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) c.r0[q] = (io.auto_reset && m.leader) ? s.robot0[m.ee * 9 + q] : 0.0;
+#pragma unroll
+  for (int t = 0; t < EBC_MAXT; ++t) {
+    const int r = m.i + t * s.N;
+    const bool st = m.env_ok && (io.ob || io.obs_rotated) && r >= m.n && r - m.n < m.ns;
+    const size_t q = m.ee * s.S + (st ? r - m.n : 0);
+    c.sx[t] = st ? s.spx[q] : 0.0;
+    c.sy[t] = st ? s.spy[q] : 0.0;
+    c.sr[t] = st ? s.sradius[q] : 0.0;
+  }
+  return c;
+}
+
+__device__ __forceinline__ void pin_loads(HumanRegs &h, CommitPre &c, double (&rb)[9], double &gtime) {
+  pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.gx); pin(h.gy); pin(h.rad); pin(h.vpref);
+  pin(h.arrival); pin(h.type);
+  pin(c.px0); pin(c.py0); pin(c.vx0); pin(c.vy0);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) { pin(c.r0[q]); pin(rb[q]); }
+#pragma unroll
+  for (int t = 0; t < EBC_MAXT; ++t) { pin(c.sx[t]); pin(c.sy[t]); pin(c.sr[t]); }
+  pin(gtime);
+}
+
+// Where service_commit stores, as VGPR addresses fixed at the start of the kernel.
+struct CommitAddr {
+  double *px, *py, *vx, *vy, *arrival, *robot, *time, *human_action, *ob;
+  float *fpx, *fpy, *fvx, *fvy, *frad, *fmax, *fprefx, *fprefy, *obs;
+};
+__device__ __forceinline__ CommitAddr commit_addr(const DevState &s, const StepIO &io, const LaneMap &m) {
+  CommitAddr a;
+  a.px = s.px + m.k; a.py = s.py + m.k; a.vx = s.vx + m.k; a.vy = s.vy + m.k;
+  a.arrival = s.arrival + m.k;
+  a.robot = s.robot + m.ee * 9;
+  a.time = s.time + m.ee;
+  a.human_action = io.human_action ? io.human_action + m.k * 2 : nullptr;
+  a.ob = io.ob ? io.ob + m.ee * (size_t)(s.N + s.S) * 5 : nullptr;
+  a.obs = io.obs_rotated;  // row offset depends on T: added by the caller
+  a.fpx = s.fpx + m.k; a.fpy = s.fpy + m.k; a.fvx = s.fvx + m.k; a.fvy = s.fvy + m.k;
+  a.frad = s.frad + m.k; a.fmax = s.fmax + m.k; a.fprefx = s.fprefx + m.k; a.fprefy = s.fprefy + m.k;
+  pin(a.px); pin(a.py); pin(a.vx); pin(a.vy); pin(a.arrival); pin(a.robot); pin(a.time);
+  pin(a.human_action); pin(a.ob); pin(a.obs);
+  pin(a.fpx); pin(a.fpy); pin(a.fvx); pin(a.fvy); pin(a.frad); pin(a.fmax); pin(a.fprefx); pin(a.fprefy);
+  return a;
+}
+
+// Leader lanes return the step's done flag and leave the robot's NEXT state in rb.
+__device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s, const StepIO &io,
+                                           const LaneMap &m, const HumanRegs &h, double rb[9],
+                                           double gtime, int lane) {
+  __shared__ double sh_d[EBC_WAVE];
+  __shared__ double sh_ract[EBC_WAVE][2];
+  __shared__ uint8_t sh_type[EBC_WAVE];
+  const double dt = p.time_step;
+  if (m.leader) {
+    double a0, a1;
+    if (io.robot_policy == EBC_ROBOT_LINEAR) {
+      linear_policy(rb[0], rb[1], rb[5], rb[6], rb[7], a0, a1);
+    } else {
+      a0 = io.robot_action[2 * m.ee];
+      a1 = io.robot_action[2 * m.ee + 1];
+    }
+    sh_ract[m.el][0] = a0;
+    sh_ract[m.el][1] = a1;
+  }
+  wave_sync();
+  const double a0 = sh_ract[m.env_ok ? m.el : 0][0], a1 = sh_ract[m.env_ok ? m.el : 0][1];
+  double rvx, rvy;
+  if (p.robot_kinematics == EBC_HOLONOMIC) {
+    rvx = a0;
+    rvy = a1;
+  } else {
+    rvx = a0 * cos(a1 + rb[8]);
+    rvy = a0 * sin(a1 + rb[8]);
+  }
+  sh_d[lane] = m.active ? closest_dist(h.px, h.py, h.vx, h.vy, h.rad, rb[0], rb[1], rb[4], rvx, rvy, dt) : 0.0;
+  sh_type[lane] = (uint8_t)h.type;
+  wave_sync();
+  if (!m.leader) return 0;
+  // ordered per-type reduction with break at the first hit (env.py:303-313)
+  double dm0 = INFINITY, dm1 = INFINITY, dm2 = INFINITY;
+  int c0 = 0, c1 = 0, c2 = 0;
+  for (int q = 0; q < m.n; ++q) {
+    const int t = sh_type[lane + q];
+    const double d = sh_d[lane + q];
+    const bool hit = d < 0;
+    if (t == 0 && !c0) { c0 = hit; dm0 = (!hit && d < dm0) ? d : dm0; }
+    if (t == 1 && !c1) { c1 = hit; dm1 = (!hit && d < dm1) ? d : dm1; }
+    if (t == 2 && !c2) { c2 = hit; dm2 = (!hit && d < dm2) ? d : dm2; }
+  }
+  const double dmin[3] = {dm0, dm1, dm2};
+  double nx, ny;
+  robot_next_position(rb, p.robot_kinematics, a0, a1, dt, nx, ny);
+  int coll[4] = {c0, c1, c2, 0};
+  coll[3] = grid_collision(s.grid ? s.grid + m.ee * s.G * 2 : nullptr, s.G, p.map_size_m,
+                           p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
+  const RewardOut ro = reward_compute(p, nx, ny, rb[5], rb[6], rb[4], a1, gtime, dmin, coll);
+  // Agent.step for the robot (agent.py:202-228)
+  rb[0] = nx;
+  rb[1] = ny;
+  if (p.robot_kinematics == EBC_HOLONOMIC) {
+    rb[2] = a0;
+    rb[3] = a1;
+  } else {
+    rb[8] = py_mod(rb[8] + a1, 2 * M_PI);
+    rb[2] = a0 * cos(rb[8]);
+    rb[3] = a0 * sin(rb[8]);
+  }
+  s.done[m.ee] = (uint8_t)ro.done;
+  if (io.reward) io.reward[m.ee] = ro.reward;
+  if (io.done) io.done[m.ee] = (uint8_t)ro.done;
+  if (io.info) io.info[m.ee] = (uint8_t)ro.info;
+  if (io.dmin) {
+    io.dmin[3 * m.ee] = dm0;
+    io.dmin[3 * m.ee + 1] = dm1;
+    io.dmin[3 * m.ee + 2] = dm2;
+  }
+  if (io.dist_to_goal) io.dist_to_goal[m.ee] = ro.dist_to_goal;
+  if (io.robot_action_out) {
+    io.robot_action_out[2 * m.ee] = a0;
+    io.robot_action_out[2 * m.ee + 1] = a1;
+  }
+  return ro.done;
+}
+
+// rbn: the robot's next state (in registers); (ax, ay): this human's velocity.
+template <int T>
+__device__ __forceinline__ void service_commit(const EbcParams &p, const DevState &s, const StepIO &io,
+                                               const LaneMap &m, HumanRegs h, const CommitPre &pre,
+                                               const CommitAddr &A, const double (&rbn)[9],
+                                               bool restore, double tnew, double ax, double ay) {
   const int N = s.N, S = s.S, R = N + S;
   const double dt = p.time_step;
-  if (!m.env_ok) return;
-  const size_t e = (size_t)m.e;
-  double rbn[9];
-  const double *rbp = s.robot_n + e * 9;
+  if (m.leader) {
+    // the robot: the moved state, or the reset() scene after a terminal step
 #pragma unroll
-  for (int c = 0; c < 9; ++c) rbn[c] = rbp[c];
-  const double tnew = s.time_n[e];
-  const bool restore = io.auto_reset && s.done[e];
-  const int ns = S ? s.n_static[e] : 0;
-
-  double px = 0, py = 0, vx = 0, vy = 0, gx = 0, gy = 0, rad = 0, vpref = 0, arrival = 0, ax = 0, ay = 0;
-  int type = 0;
-  if (m.active) {
-    px = s.px[m.k];
-    py = s.py[m.k];
-    gx = s.gx[m.k];
-    gy = s.gy[m.k];
-    rad = s.radius[m.k];
-    vpref = s.v_pref[m.k];
-    type = s.type[m.k];
-    arrival = s.arrival[m.k];
-    if (POLICY == EBC_HUMAN_LINEAR) {
-      linear_policy(px, py, gx, gy, vpref, ax, ay);  // on the pre-step state (env.py:393-405)
-    } else {
-      ax = s.hact[m.k * 2];
-      ay = s.hact[m.k * 2 + 1];
-    }
-    // Agent.step (agent.py:202-211), first arrival (env.py:365-378)
-    px = px + ax * dt;
-    py = py + ay * dt;
-    vx = ax;
-    vy = ay;
-    if (arrival == 0 && norm2(px - gx, py - gy) < rad) arrival = tnew;
+    for (int c = 0; c < 9; ++c) A.robot[c] = restore ? pre.r0[c] : rbn[c];
+    *A.time = restore ? 0.0 : tnew;
   }
-  if (io.human_action) {
-    io.human_action[m.k * 2] = ax;
-    io.human_action[m.k * 2 + 1] = ay;
+  if (m.active) {  // Agent.step (agent.py:202-211), first arrival (env.py:365-378)
+    h.px = h.px + ax * dt;
+    h.py = h.py + ay * dt;
+    h.vx = ax;
+    h.vy = ay;
+    if (h.arrival == 0 && norm2(h.px - h.gx, h.py - h.gy) < h.rad) h.arrival = tnew;
+  } else {
+    ax = 0;
+    ay = 0;
   }
-
+  if (A.human_action) {
+    A.human_action[0] = ax;
+    A.human_action[1] = ay;
+  }
   // returned observation: humans then static rows, raw and in the robot frame
   if (io.ob || io.obs_rotated) {
     const RotFrame f = rot_frame(rbn, p.rotate_unicycle);
-    for (int r = m.i; r < R; r += N) {
+    int t = 0;
+    for (int r = m.i; r < R; r += N, ++t) {
       double opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
       int otype = 0;
       bool valid = false;
       if (r < m.n) {  // r == i: this lane's own human
-        opx = px; opy = py; ovx = vx; ovy = vy; orad = rad; otype = type;
+        opx = h.px; opy = h.py; ovx = h.vx; ovy = h.vy; orad = h.rad; otype = h.type;
         valid = true;
-      } else if (r - m.n < ns) {
-        const size_t q = e * S + (r - m.n);
-        opx = s.spx[q]; opy = s.spy[q]; orad = s.sradius[q]; otype = EBC_ADULT_STATIC;
+      } else if (r - m.n < m.ns) {
+        if (t < EBC_MAXT) {
+          opx = t == 0 ? pre.sx[0] : t == 1 ? pre.sx[1] : t == 2 ? pre.sx[2] : pre.sx[3];
+          opy = t == 0 ? pre.sy[0] : t == 1 ? pre.sy[1] : t == 2 ? pre.sy[2] : pre.sy[3];
+          orad = t == 0 ? pre.sr[0] : t == 1 ? pre.sr[1] : t == 2 ? pre.sr[2] : pre.sr[3];
+        } else {
+          const size_t q = m.ee * S + (r - m.n);
+          opx = s.spx[q]; opy = s.spy[q]; orad = s.sradius[q];
+        }
+        otype = EBC_ADULT_STATIC;
         valid = true;
       }
-      const size_t row = e * R + r;
-      if (io.ob) {
-        double *o = io.ob + row * 5;
+      if (A.ob) {
+        double *o = A.ob + (size_t)r * 5;
         o[0] = opx; o[1] = opy; o[2] = ovx; o[3] = ovy; o[4] = orad;
       }
-      if (io.obs_rotated) {
+      if (A.obs) {
         float out[T];
         if (valid) {
           rotate_row<T>(f, opx, opy, ovx, ovy, orad, otype, out);
@@ -366,36 +458,171 @@ __global__ __launch_bounds__(EBC_WAVE) void phase2_kernel(EbcParams p, DevState 
 #pragma unroll
           for (int c = 0; c < T; ++c) out[c] = 0.0f;
         }
-        float *o = io.obs_rotated + row * T;
+        float *o = A.obs + (m.ee * R + r) * T;
 #pragma unroll
         for (int c = 0; c < T; ++c) o[c] = out[c];
       }
     }
   }
-
-  // commit: the moved state, or the reset() scene when this step was terminal and auto-reset is on
+  // the humans: the moved state, or the reset() scene after a terminal step
   if (m.active) {
     if (restore) {
-      px = s.px0[m.k];
-      py = s.py0[m.k];
-      vx = s.vx0[m.k];
-      vy = s.vy0[m.k];
-      arrival = 0;
+      h.px = pre.px0;
+      h.py = pre.py0;
+      h.vx = pre.vx0;
+      h.vy = pre.vy0;
+      h.arrival = 0;
     }
-    s.px[m.k] = px;
-    s.py[m.k] = py;
-    s.vx[m.k] = vx;
-    s.vy[m.k] = vy;
-    s.arrival[m.k] = arrival;
-    store_tile(p, s, m.k, px, py, vx, vy, gx, gy, rad, vpref);
+    *A.px = h.px;
+    *A.py = h.py;
+    *A.vx = h.vx;
+    *A.vy = h.vy;
+    *A.arrival = h.arrival;
+    float prefx, prefy;  // the float tile entry (store_tile), through the pinned addresses
+    orca_pref_velocity(h.px, h.py, h.gx, h.gy, prefx, prefy);
+    *A.fpx = (float)h.px;
+    *A.fpy = (float)h.py;
+    *A.fvx = (float)h.vx;
+    *A.fvy = (float)h.vy;
+    *A.frad = (float)(h.rad + 0.01 + p.orca_safety_space);
+    *A.fmax = (float)h.vpref;
+    *A.fprefx = prefx;
+    *A.fprefy = prefy;
   }
-  if (m.leader && restore) {
-    const double *r0 = s.robot0 + e * 9;
-    double *rw = s.robot_n + e * 9;
+}
+
+__device__ __forceinline__ void load_robot(const DevState &s, const LaneMap &m, double rb[9]) {
+  const double *rb_in = s.robot + m.ee * 9;
 #pragma unroll
-    for (int c = 0; c < 9; ++c) rw[c] = r0[c];
-    s.time_n[e] = 0.0;
+  for (int c = 0; c < 9; ++c) rb[c] = m.env_ok ? rb_in[c] : 0.0;
+}
+
+// Service-only step (humans on the linear policy, or velocities supplied / cached in hact): ONE
+// launch of one-wave workgroups, service_env then service_commit in the same wave.
+template <int POLICY, int T>
+__global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState s_in, StepIO io_in) {
+  const int lane = threadIdx.x;
+  __shared__ ArgBlock args;
+  __shared__ double sh_rbn[EBC_WAVE][9];
+  stage_args(&args.p, p_in, lane);
+  stage_args(&args.s, s_in, lane);
+  stage_args(&args.io, io_in, lane);
+  wave_sync();
+  const EbcParams &p = args.p;
+  const DevState &s = args.s;
+  const StepIO &io = args.io;
+  const int epb = EBC_WAVE / s.N;
+  const LaneMap m = lane_map(s, blockIdx.x * epb, epb, lane);
+  double rb[9];
+  load_robot(s, m, rb);
+  double gtime = m.env_ok ? s.time[m.ee] : 0.0;
+  HumanRegs h = load_human(s, m);
+  CommitPre pre = preload_commit(s, io, m);
+  const CommitAddr A = commit_addr(s, io, m);
+  double ax = 0, ay = 0;
+  if (POLICY == EBC_HUMAN_LINEAR) {
+    if (m.active) linear_policy(h.px, h.py, h.gx, h.gy, h.vpref, ax, ay);  // pre-step state (env.py:393-405)
+  } else if (m.env_ok) {
+    ax = s.hact[m.k * 2];
+    ay = s.hact[m.k * 2 + 1];
   }
+  pin_loads(h, pre, rb, gtime);  // every load of the step is back before its first store
+  pin(ax);
+  pin(ay);
+  int done_flag = service_env(p, s, io, m, h, rb, gtime, lane);
+  if (m.leader) {
+#pragma unroll
+    for (int c = 0; c < 9; ++c) sh_rbn[m.el][c] = rb[c];
+  }
+  // every lane of an env learns whether the step was terminal (leader = first lane of the env)
+  done_flag = __shfl(done_flag, lane - m.i, EBC_WAVE);
+  wave_sync();  // sh_rbn
+  if (!m.env_ok) return;
+  double rbn[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) rbn[c] = sh_rbn[m.el][c];
+  service_commit<T>(p, s, io, m, h, pre, A, rbn, io.auto_reset && done_flag, gtime + p.time_step, ax, ay);
+}
+
+// ORCA step: TWO launches.
+//   phase1_kernel  heterogeneous grid of one-wave workgroups: [0, env_blocks) run service_env
+//                  (6 envs per wave at N = 10: the serial robot-side work at full lane use),
+//                  the rest are ORCA waves -> hact.  Both read only pre-step state, so the
+//                  service work hides behind the ORCA waves.
+//   phase2_kernel  service_commit from hact.
+template <int GS>
+__global__ __launch_bounds__(EBC_WAVE) void phase1_kernel(EbcParams p_in, DevState s_in, StepIO io_in, int env_blocks) {
+  __shared__ __align__(16) unsigned char scratch[EBC_ORCA_LDS];
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x >= env_blocks) {
+    constexpr int HPW = EBC_WAVE / GS;
+    const int group = lane / GS, j = lane - group * GS;
+    const long hh = (long)(blockIdx.x - env_blocks) * HPW + group;
+    const bool h_ok = hh < (long)s_in.E * s_in.N;
+    const int e = h_ok ? (int)(hh / s_in.N) : 0;
+    const int i = h_ok ? (int)(hh - (long)e * s_in.N) : 0;
+    float ox, oy;
+    bool human_ok;
+    orca_wave<GS>(p_in, s_in, h_ok, e, i, scratch, ox, oy, human_ok);
+    if (h_ok && j == 0) {
+      s_in.hact[(size_t)hh * 2] = human_ok ? (double)ox : 0.0;
+      s_in.hact[(size_t)hh * 2 + 1] = human_ok ? (double)oy : 0.0;
+    }
+    return;
+  }
+  __shared__ ArgBlock args;
+  stage_args(&args.p, p_in, lane);
+  stage_args(&args.s, s_in, lane);
+  stage_args(&args.io, io_in, lane);
+  wave_sync();
+  const EbcParams &p = args.p;
+  const DevState &s = args.s;
+  const StepIO &io = args.io;
+  const int epb = EBC_WAVE / s.N;
+  const LaneMap m = lane_map(s, blockIdx.x * epb, epb, lane);
+  double rb[9];
+  load_robot(s, m, rb);
+  double gtime = m.env_ok ? s.time[m.ee] : 0.0;
+  HumanRegs h = load_human(s, m);
+  pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type); pin(gtime);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) pin(rb[q]);
+  service_env(p, s, io, m, h, rb, gtime, lane);
+  if (m.leader) {  // the robot's next state waits in scratch for phase 2 (ORCA waves may read s.robot)
+    double *o = s.robot_n + m.ee * 9;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) o[c] = rb[c];
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(EBC_WAVE) void phase2_kernel(EbcParams p_in, DevState s_in, StepIO io_in) {
+  const int lane = threadIdx.x;
+  __shared__ ArgBlock args;
+  stage_args(&args.p, p_in, lane);
+  stage_args(&args.s, s_in, lane);
+  stage_args(&args.io, io_in, lane);
+  wave_sync();
+  const EbcParams &p = args.p;
+  const DevState &s = args.s;
+  const StepIO &io = args.io;
+  const int epb = EBC_WAVE / s.N;
+  const LaneMap m = lane_map(s, blockIdx.x * epb, epb, lane);
+  if (!m.env_ok) return;
+  HumanRegs h = load_human(s, m);
+  CommitPre pre = preload_commit(s, io, m);
+  const CommitAddr A = commit_addr(s, io, m);
+  double gtime = s.time[m.ee];
+  int done_flag = s.done[m.ee];
+  double ax = s.hact[m.k * 2], ay = s.hact[m.k * 2 + 1];
+  double rbn[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) rbn[c] = s.robot_n[m.ee * 9 + c];
+  pin_loads(h, pre, rbn, gtime);
+  pin(ax);
+  pin(ay);
+  pin(done_flag);
+  service_commit<T>(p, s, io, m, h, pre, A, rbn, io.auto_reset && done_flag, gtime + p.time_step, ax, ay);
 }
 
 // ------------------------------------------------------------------------- look-ahead

@@ -18,6 +18,15 @@
 
 namespace ebc {
 
+// LDS scratch is private to a wave and a wave's LDS instructions execute in order, so lanes of
+// one wave only need the COMPILER to keep a write before the reads that follow it; no
+// s_barrier (workgroups of several waves run different numbers of these).
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- group collectives (all lanes of the group are active together) -----------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v) {
@@ -155,7 +164,7 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
   const float distSqN = ddx * ddx + ddy * ddy;
   const bool inRange = valid && distSqN < rangeSq;
   dist_lds[j] = inRange ? distSqN : INFINITY;
-  __syncthreads();
+  wave_sync();
   int rank = 0;
 #pragma unroll
   for (int k4 = 0; k4 < GS / 4; ++k4) {
@@ -218,7 +227,7 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
     }
     lines_lds[rank] = make_float4(velx + 0.5f * ux, vely + 0.5f * uy, dirx, diry);
   }
-  __syncthreads();
+  wave_sync();
   Line4 own{0, 0, 0, 0};
   if (j < nn) {
     const float4 q = lines_lds[j];
@@ -228,29 +237,18 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
   float rx, ry;
   const int lineFail = lp2_group<GS>(own, j, lines_lds, nn, maxSpeed, prefx, prefy, false, group, rx, ry);
 
-  // linearProgram3 (numObstLines = 0): only groups whose LP2 failed enter; the loop bounds are
-  // group-uniform, the __syncthreads below are reached by every lane of the wave the same
-  // number of times because the trip count is made wave-uniform.
-  const int fail_lo = lineFail < nn ? lineFail : nn;
-  const int any_fail = __any(lineFail < nn);
-  if (any_fail) {
+  // linearProgram3 (numObstLines = 0): only groups whose LP2 failed enter; every bound below is
+  // group-uniform
+  if (lineFail < nn) {
     float distance = 0.0f;
-    // wave-uniform trip count: the largest nn in the wave
-    int nn_max = nn;
-#pragma unroll
-    for (int m = GS; m < 64; m <<= 1) nn_max = max(nn_max, __shfl_xor(nn_max, m, 64));
-    for (int i = 0; i < nn_max; ++i) {
-      const bool act = i >= fail_lo && i < nn;  // group-uniform
-      Line4 li{0, 0, 0, 0};
-      if (act) {
-        const float4 q = lines_lds[i];
-        li = Line4{q.x, q.y, q.z, q.w};
-      }
-      const bool run = act && det2(li.dx, li.dy, li.px - rx, li.py - ry) > distance;
+    for (int i = lineFail; i < nn; ++i) {
+      const float4 qi = lines_lds[i];
+      const Line4 li{qi.x, qi.y, qi.z, qi.w};
+      if (!(det2(li.dx, li.dy, li.px - rx, li.py - ry) > distance)) continue;
       // projected lines of lanes j < i, compacted in lane order (the serial push_back order)
       bool keep = false;
       float qx = 0, qy = 0;
-      if (run && j < i) {
+      if (j < i) {
         const float determinant = det2(li.dx, li.dy, own.dx, own.dy);
         if (fabsf(determinant) <= RVO_EPS) {
           if (!(li.dx * own.dx + li.dy * own.dy > 0.0f)) {
@@ -267,26 +265,24 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
       }
       const unsigned km = group_ballot<GS>(keep, group);
       const int np = __popc(km);
+      wave_sync();  // the previous round's reads of proj_lds are done
       if (keep) {
         const float ex = own.dx - li.dx, ey = own.dy - li.dy;
         const float inv = 1.0f / sqrtf(ex * ex + ey * ey);
         proj_lds[__popc(km & ((1u << j) - 1u))] = make_float4(qx, qy, ex * inv, ey * inv);
       }
-      __syncthreads();
-      if (run) {
-        Line4 pown{0, 0, 0, 0};
-        if (j < np) {
-          const float4 q = proj_lds[j];
-          pown = Line4{q.x, q.y, q.z, q.w};
-        }
-        float tx = rx, ty = ry;
-        if (lp2_group<GS>(pown, j, proj_lds, np, maxSpeed, -li.dy, li.dx, true, group, tx, ty) >= np) {
-          rx = tx;
-          ry = ty;
-        }
-        distance = det2(li.dx, li.dy, li.px - rx, li.py - ry);
+      wave_sync();
+      Line4 pown{0, 0, 0, 0};
+      if (j < np) {
+        const float4 q = proj_lds[j];
+        pown = Line4{q.x, q.y, q.z, q.w};
       }
-      __syncthreads();
+      float tx = rx, ty = ry;
+      if (lp2_group<GS>(pown, j, proj_lds, np, maxSpeed, -li.dy, li.dx, true, group, tx, ty) >= np) {
+        rx = tx;
+        ry = ty;
+      }
+      distance = det2(li.dx, li.dy, li.px - rx, li.py - ry);
     }
   }
   out_x = rx;

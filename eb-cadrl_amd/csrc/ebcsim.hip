@@ -43,7 +43,7 @@ struct Handle {
   hipStream_t stream = nullptr;
   bool has_reset = false;
   bool has_grid = false;
-  int orca_gs = 16;  // lanes per human of the ORCA role (8 / 16 / 32 / 64)
+  int orca_gs = 16;  // lanes per human of the ORCA waves (8 / 16 / 32)
   uint64_t *grid_alloc = nullptr;
   // staging for host-location calls
   void *stage = nullptr;
@@ -118,21 +118,41 @@ int check_handle(void *handle, Handle **out) {
   return EBC_OK;
 }
 
-int human_blocks(const Handle *h) {
-  const int epb = EBC_WAVE / h->s.N;
-  return (h->s.E + epb - 1) / epb;
-}
-
 int orca_blocks(const Handle *h) {
   const long humans = (long)h->s.E * h->s.N;
   const int hpw = EBC_WAVE / h->orca_gs;
   return (int)((humans + hpw - 1) / hpw);
 }
 
-// phase 1: ENV role on `env_blocks` workgroups, ORCA role on `orca` more
-int launch_phase1(Handle *h, const StepIO &io, int env_blocks, int orca) {
-  const int blocks = env_blocks + orca;
-  if (blocks == 0) return EBC_OK;
+int launch_orca(Handle *h) {
+  const int blocks = orca_blocks(h);
+#define OK_(GS) hipLaunchKernelGGL((ebc::orca_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s)
+  switch (h->orca_gs) {
+    case 8: OK_(8); break;
+    case 16: OK_(16); break;
+    default: OK_(32); break;
+  }
+#undef OK_
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+template <int POLICY>
+int launch_service(Handle *h, const StepIO &io) {
+  const int epb = EBC_WAVE / h->s.N;
+  const int blocks = (h->s.E + epb - 1) / epb;
+  if (h->T == 17)
+    hipLaunchKernelGGL((ebc::step_kernel<POLICY, 17>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+  else
+    hipLaunchKernelGGL((ebc::step_kernel<POLICY, 13>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+int launch_orca_step(Handle *h, const StepIO &io) {
+  const int epb = EBC_WAVE / h->s.N;
+  const int env_blocks = (h->s.E + epb - 1) / epb;
+  const int blocks = env_blocks + orca_blocks(h);
 #define P1_(GS) hipLaunchKernelGGL((ebc::phase1_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, env_blocks)
   switch (h->orca_gs) {
     case 8: P1_(8); break;
@@ -141,18 +161,18 @@ int launch_phase1(Handle *h, const StepIO &io, int env_blocks, int orca) {
   }
 #undef P1_
   HIP_TRY(hipGetLastError());
+  if (h->T == 17)
+    hipLaunchKernelGGL((ebc::phase2_kernel<17>), dim3(env_blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+  else
+    hipLaunchKernelGGL((ebc::phase2_kernel<13>), dim3(env_blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+  HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
 
-template <int POLICY>
-int launch_phase2(Handle *h, const StepIO &io) {
-  const int blocks = human_blocks(h);
-  if (h->T == 17)
-    hipLaunchKernelGGL((ebc::phase2_kernel<POLICY, 17>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
-  else
-    hipLaunchKernelGGL((ebc::phase2_kernel<POLICY, 13>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
-  HIP_TRY(hipGetLastError());
-  return EBC_OK;
+int launch_step(Handle *h, const StepIO &io, int policy) {
+  if (policy == EBC_HUMAN_ORCA) return launch_orca_step(h, io);
+  if (policy == EBC_HUMAN_LINEAR) return launch_service<EBC_HUMAN_LINEAR>(h, io);
+  return launch_service<EBC_HUMAN_EXTERNAL>(h, io);
 }
 
 template <int POLICY>
@@ -234,8 +254,7 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
 #define A_(field, cnt) if (rc == EBC_OK) rc = dev_alloc(h, &s.field, (cnt))
   A_(n_humans, n_envs); A_(px, EN); A_(py, EN); A_(vx, EN); A_(vy, EN); A_(gx, EN); A_(gy, EN);
   A_(radius, EN); A_(v_pref, EN); A_(type, EN); A_(n_static, n_envs); A_(spx, ES); A_(spy, ES);
-  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs);
-  A_(time_n, n_envs); A_(arrival, EN); A_(fpx, EN); A_(fpy, EN); A_(fvx, EN); A_(fvy, EN); A_(frad, EN);
+  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN); A_(fpx, EN); A_(fpy, EN); A_(fvx, EN); A_(fvy, EN); A_(frad, EN);
   A_(fmax, EN); A_(fprefx, EN); A_(fprefy, EN);
   A_(done, n_envs); A_(hact, EN * 2); A_(px0, EN); A_(py0, EN); A_(vx0, EN); A_(vy0, EN);
   A_(robot0, (size_t)n_envs * 9);
@@ -453,14 +472,7 @@ int ebc_step(void *handle, const EbcStepArgs *a) {
     e1 = h->ev[h->ev_used++];
     HIP_TRY(hipEventRecord(e0, h->stream));
   }
-  const bool orca = a->human_policy == EBC_HUMAN_ORCA;
-  if ((rc = launch_phase1(h, io, human_blocks(h), orca ? orca_blocks(h) : 0)) != EBC_OK) return rc;
-  rc = a->human_policy == EBC_HUMAN_LINEAR ? launch_phase2<EBC_HUMAN_LINEAR>(h, io)
-                                           : launch_phase2<EBC_HUMAN_EXTERNAL>(h, io);
-  if (rc != EBC_OK) return rc;
-  // the "next" robot / time buffers become current
-  std::swap(h->s.robot, h->s.robot_n);
-  std::swap(h->s.time, h->s.time_n);
+  if ((rc = launch_step(h, io, a->human_policy)) != EBC_OK) return rc;
   if (h->timing) HIP_TRY(hipEventRecord(e1, h->stream));
   if (a->location != EBC_DEVICE) return st.finish();
   return EBC_OK;
@@ -500,11 +512,7 @@ int ebc_lookahead(void *handle, const EbcLookaheadArgs *a) {
     io.info = st.out(a->info, E * A); io.dmin = st.out(a->dmin, E * A * 3);
     io.next_ob = st.out(a->next_ob, E * R * 5); io.rows = st.out(a->rows_rotated, E * A * R * T);
   }
-  if (a->human_policy == EBC_HUMAN_ORCA) {  // ORCA role only -> hact
-    StepIO none;
-    memset(&none, 0, sizeof(none));
-    if ((rc = launch_phase1(h, none, 0, orca_blocks(h))) != EBC_OK) return rc;
-  }
+  if (a->human_policy == EBC_HUMAN_ORCA && (rc = launch_orca(h)) != EBC_OK) return rc;  // -> hact
   rc = a->human_policy == EBC_HUMAN_LINEAR ? launch_lookahead<EBC_HUMAN_LINEAR>(h, io)
                                            : launch_lookahead<EBC_HUMAN_EXTERNAL>(h, io);
   if (rc != EBC_OK) return rc;
