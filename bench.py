@@ -163,6 +163,12 @@ def main():
         S_mean = float(batch.n_static.mean()) if batch.S else 0.0
         bytes_launch = algorithmic_bytes_per_env_step(batch.N, S_mean, env.T) * E
         achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None  # PMC-measured HBM bytes per step, from the committed profile of this workload
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath) and world == 1:
+            tj = json.load(open(tpath))
+            if tj.get("envs_per_gpu") == E:
+                traffic = tj["traffic_bytes_per_step"]
         line = {
             "metric": "agent-steps/sec", "value": total_humans * args.steps / elapsed_max,
             "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,8 +180,9 @@ def main():
                                                    "" if hp == _abi.HUMAN_ORCA else " [DIAGNOSTIC: linear humans]"),
                        "envs_per_gpu": E, "humans": int(batch.N), "parallelism": "env-slice x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "step_kernel<ORCA>", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "phase1_kernel + phase2_kernel (the two launches of one step)",
+                         "kernel_ms": kernel_ms,
                          "stream_ms_per_step": stream_ms / args.steps,
                          "algorithmic_bytes_per_launch": bytes_launch},
         }

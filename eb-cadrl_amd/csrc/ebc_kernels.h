@@ -157,10 +157,11 @@ __global__ __launch_bounds__(EBC_WAVE) void orca_kernel(EbcParams p, DevState s)
   constexpr int HPW = EBC_WAVE / GS;
   __shared__ __align__(16) unsigned char scratch[EBC_ORCA_LDS];
   const int group = threadIdx.x / GS, j = threadIdx.x - group * GS;
-  const long h = (long)blockIdx.x * HPW + group;
-  const bool h_ok = h < (long)s.E * s.N;
-  const int e = h_ok ? (int)(h / s.N) : 0;
-  const int i = h_ok ? (int)(h - (long)e * s.N) : 0;
+  const unsigned h = (unsigned)blockIdx.x * HPW + group;
+  const unsigned N = (unsigned)s.N;
+  const bool h_ok = h < (unsigned)s.E * N;
+  const int e = h_ok ? (int)(h / N) : 0;
+  const int i = h_ok ? (int)(h - (unsigned)e * N) : 0;
   float ox, oy;
   bool human_ok;
   orca_wave<GS>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
@@ -557,10 +558,12 @@ __global__ __launch_bounds__(EBC_WAVE) void phase1_kernel(EbcParams p_in, DevSta
   if ((int)blockIdx.x >= env_blocks) {
     constexpr int HPW = EBC_WAVE / GS;
     const int group = lane / GS, j = lane - group * GS;
-    const long hh = (long)(blockIdx.x - env_blocks) * HPW + group;
-    const bool h_ok = hh < (long)s_in.E * s_in.N;
-    const int e = h_ok ? (int)(hh / s_in.N) : 0;
-    const int i = h_ok ? (int)(hh - (long)e * s_in.N) : 0;
+    // 32-bit index math (E * N < 2^31 is checked at create): a 64-bit divide is ~100 instructions
+    const unsigned hh = (unsigned)(blockIdx.x - env_blocks) * HPW + group;
+    const unsigned N = (unsigned)s_in.N;
+    const bool h_ok = hh < (unsigned)s_in.E * N;
+    const int e = h_ok ? (int)(hh / N) : 0;
+    const int i = h_ok ? (int)(hh - (unsigned)e * N) : 0;
     float ox, oy;
     bool human_ok;
     orca_wave<GS>(p_in, s_in, h_ok, e, i, scratch, ox, oy, human_ok);
@@ -626,22 +629,32 @@ __global__ __launch_bounds__(EBC_WAVE) void phase2_kernel(EbcParams p_in, DevSta
 }
 
 // ------------------------------------------------------------------------- look-ahead
-// One wave per env.  Human velocities come from s.hact (ORCA role / set_human_actions), or the
-// linear policy.
-//   phase A  lanes over rows: next observable rows into LDS (agent.py:80-93; env.py:457-458)
-//   phase B  lanes over actions: ordered collisions, grid, reward, robot frame of rotate()
-//   phase C  lanes over (action, row): rotated rows
+// The |A|-way onestep_lookahead sweep of MultiHumanRL.predict (multi_human_rl.py:38-61), one
+// 256-thread workgroup per env.  Human velocities come from s.hact (ORCA kernel,
+// ebc_set_human_actions) or the linear policy, once for all actions.
+//   phase A  threads over rows: next observable rows (agent.py:80-93; env.py:457-458) -> LDS
+//   phase B1 threads over (action, human) pairs: swept distance (collisions.py:29-57) -> LDS
+//   phase B2 threads over actions: ordered per-type reduction, grid window, reward, and the
+//            robot-frame terms of rotate() for the propagated robot (cadrl.py:118-165)
+//   phase C  rows_rotated[e][a][r][:]: 256 rows at a time are rotated into an LDS tile and
+//            leave as 16-byte stores in flat order (the 4 T bytes of a row are not a
+//            multiple of 16: writing row by row costs T dword stores per lane and splits every
+//            128-B line; this is the one output of the path that is HBM-bound: 4 T A R bytes
+//            per env)
+// Dynamic LDS: A * n_max doubles (pair distances), then 256 * T floats (row tile).
+#define EBC_LA_THREADS 256
 #define EBC_LA_MAX_ROWS 128
 #define EBC_LA_MAX_ACTIONS 128
 template <int POLICY, int T>
-__global__ __launch_bounds__(EBC_WAVE) void lookahead_kernel(EbcParams p, DevState s, LookIO io) {
+__global__ __launch_bounds__(EBC_LA_THREADS) void lookahead_kernel(EbcParams p, DevState s, LookIO io) {
+  extern __shared__ __align__(16) unsigned char la_lds[];
   __shared__ double hpx[EBC_WAVE], hpy[EBC_WAVE], hvx[EBC_WAVE], hvy[EBC_WAVE], hrad[EBC_WAVE];
   __shared__ uint8_t htype[EBC_WAVE];
   __shared__ double row[EBC_LA_MAX_ROWS][5];
   __shared__ uint8_t row_type[EBC_LA_MAX_ROWS];
   __shared__ RotFrame frames[EBC_LA_MAX_ACTIONS];
   const int N = s.N, S = s.S, R = N + S, A = io.A;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
   const int e = blockIdx.x;
   const int n = s.n_humans[e];
   const int ns = S ? s.n_static[e] : 0;
@@ -650,8 +663,10 @@ __global__ __launch_bounds__(EBC_WAVE) void lookahead_kernel(EbcParams p, DevSta
   double rb[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) rb[c] = rbp[c];
+  double *dist = reinterpret_cast<double *>(la_lds);                 // [A][N]
+  float *tile = reinterpret_cast<float *>(la_lds + (size_t)A * N * 8);  // [256][T]
 
-  for (int r = lane; r < R; r += EBC_WAVE) {
+  for (int r = tid; r < R; r += EBC_LA_THREADS) {
     double o[5] = {0, 0, 0, 0, 0};
     int t = 0;
     if (r < n) {
@@ -690,8 +705,9 @@ __global__ __launch_bounds__(EBC_WAVE) void lookahead_kernel(EbcParams p, DevSta
   }
   __syncthreads();
 
-  const double gtime = s.time[e];
-  for (int a = lane; a < A; a += EBC_WAVE) {
+  // phase B1: every (action, human) pair in parallel
+  for (int q = tid; q < A * n; q += EBC_LA_THREADS) {
+    const int a = q / n, j = q - a * n;
     const double a0 = io.actions[2 * a], a1 = io.actions[2 * a + 1];
     double rvx, rvy;
     if (p.robot_kinematics == EBC_HOLONOMIC) {
@@ -701,19 +717,23 @@ __global__ __launch_bounds__(EBC_WAVE) void lookahead_kernel(EbcParams p, DevSta
       rvx = a0 * cos(a1 + rb[8]);
       rvy = a0 * sin(a1 + rb[8]);
     }
+    dist[a * N + j] = closest_dist(hpx[j], hpy[j], hvx[j], hvy[j], hrad[j], rb[0], rb[1], rb[4], rvx, rvy, dt);
+  }
+  __syncthreads();
+
+  // phase B2
+  const double gtime = s.time[e];
+  for (int a = tid; a < A; a += EBC_LA_THREADS) {
+    const double a0 = io.actions[2 * a], a1 = io.actions[2 * a + 1];
     double dm0 = INFINITY, dm1 = INFINITY, dm2 = INFINITY;
     int c0 = 0, c1 = 0, c2 = 0;
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < n; ++j) {  // index order, break at the first hit per type (env.py:303-313)
       const int t = htype[j];
-      const bool live = (t == 0 && !c0) || (t == 1 && !c1) || (t == 2 && !c2);
-      if (live) {
-        const double d = closest_dist(hpx[j], hpy[j], hvx[j], hvy[j], hrad[j], rb[0], rb[1], rb[4],
-                                      rvx, rvy, dt);
-        const bool hit = d < 0;
-        if (t == 0) { c0 = hit; dm0 = (!hit && d < dm0) ? d : dm0; }
-        if (t == 1) { c1 = hit; dm1 = (!hit && d < dm1) ? d : dm1; }
-        if (t == 2) { c2 = hit; dm2 = (!hit && d < dm2) ? d : dm2; }
-      }
+      const double d = dist[a * N + j];
+      const bool hit = d < 0;
+      if (t == 0 && !c0) { c0 = hit; dm0 = (!hit && d < dm0) ? d : dm0; }
+      if (t == 1 && !c1) { c1 = hit; dm1 = (!hit && d < dm1) ? d : dm1; }
+      if (t == 2 && !c2) { c2 = hit; dm2 = (!hit && d < dm2) ? d : dm2; }
     }
     const double dmin[3] = {dm0, dm1, dm2};
     double nx, ny;
@@ -756,19 +776,40 @@ __global__ __launch_bounds__(EBC_WAVE) void lookahead_kernel(EbcParams p, DevSta
   if (!io.rows) return;
   __syncthreads();
 
-  const int total = A * R;
-  for (int idx = lane; idx < total; idx += EBC_WAVE) {
-    const int a = idx / R, r = idx - a * R;
-    float out[T];
-    if (r < n + ns) {
-      rotate_row<T>(frames[a], row[r][0], row[r][1], row[r][2], row[r][3], row[r][4], row_type[r], out);
-    } else {
+  // phase C
+  const int total_rows = A * R;
+  const size_t env_base = (size_t)e * total_rows * T;  // in floats
+  for (int c0 = 0; c0 < total_rows; c0 += EBC_LA_THREADS) {
+    const int idx = c0 + tid;
+    if (idx < total_rows) {
+      const int a = idx / R, r = idx - a * R;
+      float out[T];
+      if (r < n + ns) {
+        rotate_row<T>(frames[a], row[r][0], row[r][1], row[r][2], row[r][3], row[r][4], row_type[r], out);
+      } else {
 #pragma unroll
-      for (int c = 0; c < T; ++c) out[c] = 0.0f;
+        for (int c = 0; c < T; ++c) out[c] = 0.0f;
+      }
+#pragma unroll
+      for (int c = 0; c < T; ++c) tile[tid * T + c] = out[c];  // stride T is odd: conflict-free
     }
-    float *dst = io.rows + ((size_t)e * A * R + idx) * T;
-#pragma unroll
-    for (int c = 0; c < T; ++c) dst[c] = out[c];
+    __syncthreads();
+    // flat copy of the chunk: floats [g0, g0 + cnt) of the output
+    const int rows_here = min(EBC_LA_THREADS, total_rows - c0);
+    const int cnt = rows_here * T;
+    const size_t g0 = env_base + (size_t)c0 * T;
+    const int head = (int)((4 - (g0 & 3)) & 3);  // floats before the first 16-byte boundary
+    float *dst = io.rows + g0;
+    if (tid < head && tid < cnt) dst[tid] = tile[tid];
+    const int body4 = cnt > head ? (cnt - head) / 4 : 0;
+    for (int v = tid; v < body4; v += EBC_LA_THREADS) {
+      const int f = head + 4 * v;
+      const float4 w = make_float4(tile[f], tile[f + 1], tile[f + 2], tile[f + 3]);
+      *reinterpret_cast<float4 *>(dst + f) = w;
+    }
+    const int tail0 = head + 4 * body4;
+    if (tail0 + tid < cnt && tid < 4) dst[tail0 + tid] = tile[tail0 + tid];
+    __syncthreads();
   }
 }
 

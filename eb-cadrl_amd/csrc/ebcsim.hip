@@ -177,10 +177,11 @@ int launch_step(Handle *h, const StepIO &io, int policy) {
 
 template <int POLICY>
 int launch_lookahead(Handle *h, const LookIO &io) {
+  const size_t lds = (size_t)io.A * h->s.N * 8 + (io.rows ? (size_t)EBC_LA_THREADS * h->T * 4 : 0);
   if (h->T == 17)
-    hipLaunchKernelGGL((ebc::lookahead_kernel<POLICY, 17>), dim3(h->s.E), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+    hipLaunchKernelGGL((ebc::lookahead_kernel<POLICY, 17>), dim3(h->s.E), dim3(EBC_LA_THREADS), lds, h->stream, h->p, h->s, io);
   else
-    hipLaunchKernelGGL((ebc::lookahead_kernel<POLICY, 13>), dim3(h->s.E), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+    hipLaunchKernelGGL((ebc::lookahead_kernel<POLICY, 13>), dim3(h->s.E), dim3(EBC_LA_THREADS), lds, h->stream, h->p, h->s, io);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
@@ -223,6 +224,7 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   if (params->struct_size != sizeof(EbcParams))
     return fail(EBC_ERR_INVALID, "EbcParams.struct_size does not match this library");
   if (n_envs <= 0 || max_humans <= 0 || max_static < 0) return fail(EBC_ERR_INVALID, "bad dimensions");
+  if ((double)n_envs * max_humans >= 2147483648.0) return fail(EBC_ERR_UNSUPPORTED, "n_envs * max_humans >= 2^31");
   if (max_humans - 1 + (params->robot_visible ? 1 : 0) > 32)
     return fail(EBC_ERR_UNSUPPORTED, "more than 32 other agents per human (ORCA group of 32 lanes)");
   if (max_humans + max_static > EBC_LA_MAX_ROWS)

@@ -185,6 +185,30 @@ class BatchedEnv:
             setattr(args, k, t.data_ptr())
         _capi.check(self._L.ebc_step(self._h, C.addressof(args)))
 
+    def alloc_lookahead_outputs(self, n_actions, keys=("reward", "done", "info", "rows_rotated")):
+        """torch CUDA tensors for lookahead_device(); the caller owns them."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        E, R, T, A = self.E, self.R, self.T, int(n_actions)
+        shapes = dict(reward=((E, A), torch.float64), done=((E, A), torch.uint8),
+                      info=((E, A), torch.uint8), dmin=((E, A, 3), torch.float64),
+                      next_ob=((E, R, 5), torch.float64), rows_rotated=((E, A, R, T), torch.float32))
+        return {k: torch.zeros(shapes[k][0], dtype=shapes[k][1], device=dev) for k in keys}
+
+    def lookahead_device(self, actions, outputs, human_policy=_abi.HUMAN_ORCA, flags=0):
+        """Enqueue the |A|-way sweep; `actions` float64 [A, 2] and `outputs` are torch CUDA tensors."""
+        args = _abi.EbcLookaheadArgs()
+        args.struct_size = C.sizeof(args)
+        args.location = _abi.DEVICE
+        args.human_policy, args.n_actions = int(human_policy), int(actions.shape[0])
+        args.flags = int(flags)
+        if actions.dtype.itemsize != 8 or actions.dim() != 2 or actions.shape[1] != 2:
+            raise ValueError("actions must be float64 [A, 2]")
+        args.actions = actions.data_ptr()
+        for k, t in outputs.items():
+            setattr(args, k, t.data_ptr())
+        _capi.check(self._L.ebc_lookahead(self._h, C.addressof(args)))
+
     def synchronize(self):
         _capi.check(self._L.ebc_synchronize(self._h))
 

@@ -52,6 +52,17 @@ def main():
         t_orca = timed(lambda: env.step_device(outs, human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=fl))
         t_lin = timed(lambda: env.step_device(outs, human_policy=_abi.HUMAN_LINEAR, robot_policy=_abi.ROBOT_LINEAR, flags=fl))
         t_ext = timed(lambda: env.step_device(outs, human_policy=_abi.HUMAN_CACHED, robot_policy=_abi.ROBOT_LINEAR, flags=fl))
+        acts = torch.tensor(space, dtype=torch.float64, device="cuda")
+        lo = env.alloc_lookahead_outputs(len(space), ("reward", "done", "info"))
+        t_la = timed(lambda: env.lookahead_device(acts, lo, human_policy=_abi.HUMAN_ORCA), n=30)
+        t_rows = float("nan")
+        if E * len(space) * env.R * env.T * 4 < 3e9:
+            lr = env.alloc_lookahead_outputs(len(space), ("reward", "done", "info", "rows_rotated"))
+            t_rows = timed(lambda: env.lookahead_device(acts, lr, human_policy=_abi.HUMAN_ORCA), n=20)
+            gb = E * len(space) * env.R * env.T * 4 / 1e9
+            print("E %6d lookahead[81, no rows] %8.2f us   lookahead[81, rows %.3f GB] %8.2f us = %.0f GB/s"
+                  % (E, t_la, gb, t_rows, gb / (t_rows * 1e-6)), flush=True)
+            del lr
         print("E %6d N %d  step[orca] %8.2f us  step[linear] %8.2f us  step[cached] %8.2f us  -> orca role ~%8.2f us"
               % (E, b.N, t_orca, t_lin, t_ext, t_orca - t_ext), flush=True)
         env.close()
