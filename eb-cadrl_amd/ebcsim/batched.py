@@ -76,6 +76,10 @@ class BatchedEnv:
             if len(ids) != scene.n:
                 raise ValueError("len(env_ids) != scene.n")
         _capi.check(self._L.ebc_reset(self._h, _np_ptr(ids), C.addressof(sc)))
+        if not hasattr(self, "n_static_host"):
+            self.n_static_host = np.zeros(self.E, dtype=np.int64)
+        if self.S:
+            self.n_static_host[np.arange(scene.n) if ids is None else ids] = scene.n_static
 
     # ------------------------------------------------------------------ host calls
     def set_human_actions(self, act):

@@ -1,0 +1,115 @@
+"""The robot's decision on device: look-ahead sweep + SARL value network + argmax.
+
+What MultiHumanRL.predict does per decision in the reference (rl/policy/multi_human_rl.py:12-87):
+for each of the 81 actions, env.onestep_lookahead -> rotate -> model -> value.  Here the sweep is
+one ebc_lookahead launch that leaves rows_rotated[E][A][R][T] in HBM, and the value network
+(rl/policy/sarl.py:38-82) runs on those rows as batched torch GEMMs (hipBLASLt on ROCm).  The
+network is rebuilt functionally from the reference's state_dict, so its .pth files load as they
+are.  Rows beyond an env's n_humans + n_static are masked out of the mean / softmax (the
+reference never creates them)."""
+import numpy as np
+import torch
+
+from . import _abi
+
+
+def _mlp(x, layers, last_relu):
+    for i, (w, b) in enumerate(layers):
+        x = torch.nn.functional.linear(x, w, b)
+        if i != len(layers) - 1 or last_relu:
+            x = torch.relu(x)
+    return x
+
+
+class SarlValueNet(object):
+    """rl/policy/sarl.py:9-82 (ValueNetwork), weights from its state_dict."""
+
+    def __init__(self, state_dict, device="cpu", with_global_state=True, self_state_dim=6):
+        def stack(prefix):
+            idx = sorted({int(k.split(".")[1]) for k in state_dict if k.startswith(prefix + ".")})
+            return [(state_dict["%s.%d.weight" % (prefix, i)].to(device=device, dtype=torch.float32),
+                     state_dict["%s.%d.bias" % (prefix, i)].to(device=device, dtype=torch.float32))
+                    for i in idx]
+        self.mlp1, self.mlp2 = stack("mlp1"), stack("mlp2")
+        self.attention, self.mlp3 = stack("attention"), stack("mlp3")
+        self.with_global_state = with_global_state
+        self.self_state_dim = self_state_dim
+        self.input_dim = self.mlp1[0][0].shape[1]
+        self.device = torch.device(device)
+
+    @classmethod
+    def load(cls, path, device="cpu", **kw):
+        return cls(torch.load(path, map_location="cpu"), device=device, **kw)
+
+    @torch.no_grad()
+    def forward(self, rows, n_valid=None):
+        """rows [B, R, T] float32; n_valid [B] (rows that exist) or None = all -> values [B]."""
+        B, R, T = rows.shape
+        self_state = rows[:, 0, :self.self_state_dim]
+        h1 = _mlp(rows.reshape(B * R, T), self.mlp1, True)
+        feat = _mlp(h1, self.mlp2, False).view(B, R, -1)
+        if n_valid is None:
+            valid = None
+            denom = float(R)
+        else:
+            valid = (torch.arange(R, device=rows.device)[None, :] < n_valid[:, None])
+            denom = n_valid.to(torch.float32).clamp(min=1)[:, None, None]
+        if self.with_global_state:
+            h1v = h1.view(B, R, -1)
+            if valid is not None:
+                h1v = h1v * valid[:, :, None]
+            g = (h1v.sum(1, keepdim=True) / denom).expand(B, R, h1v.shape[2])
+            att_in = torch.cat([h1.view(B, R, -1), g], dim=2).reshape(B * R, -1)
+        else:
+            att_in = h1
+        scores = _mlp(att_in, self.attention, False).view(B, R)
+        e = torch.exp(scores) * (scores != 0).float()  # the reference's masked softmax (sarl.py:69-70)
+        if valid is not None:
+            e = e * valid
+        w = (e / e.sum(dim=1, keepdim=True)).unsqueeze(2)
+        joint = torch.cat([self_state, (w * feat).sum(dim=1)], dim=1)
+        return _mlp(joint, self.mlp3, False).squeeze(1)
+
+
+class DeviceSarlPolicy(object):
+    """Greedy SARL decisions for a whole BatchedEnv (phase "test": no epsilon draw)."""
+
+    def __init__(self, net, actions, gamma, chunk_rows=1 << 19):
+        self.net = net
+        self.actions_np = np.ascontiguousarray(actions, dtype=np.float64)
+        self.gamma = float(gamma)
+        self.chunk_rows = int(chunk_rows)
+        self._bufs = None
+
+    def values_from(self, rows, reward, n_valid, dt, v_pref):
+        """rows [E, A, R, T] float32, reward [E, A] float64 -> values [E, A] float64
+        (multi_human_rl.py:72-76: reward + gamma^(dt * v_pref) * V)."""
+        E, A, R, T = rows.shape
+        per_env = A * R
+        step = max(1, self.chunk_rows // per_env)
+        out = torch.empty((E, A), dtype=torch.float32, device=rows.device)
+        for e0 in range(0, E, step):
+            e1 = min(E, e0 + step)
+            nv = None if n_valid is None else n_valid[e0:e1].repeat_interleave(A)
+            out[e0:e1] = self.net.forward(rows[e0:e1].reshape(-1, R, T), nv).view(e1 - e0, A)
+        return reward + (self.gamma ** (dt * v_pref)) * out.to(torch.float64)
+
+    def decide(self, env, human_policy=_abi.HUMAN_ORCA):
+        """env: BatchedEnv on this net's device.  Returns (actions [E, 2] float64 CUDA tensor,
+        values [E, A]); the human velocities stay cached for a following EBC_HUMAN_CACHED step."""
+        dev = self.net.device
+        A = len(self.actions_np)
+        if self._bufs is None:
+            self._acts = torch.tensor(self.actions_np, dtype=torch.float64, device=dev)
+            self._bufs = env.alloc_lookahead_outputs(A, ("reward", "rows_rotated"))
+            st = env.get_state()
+            nv = st["n_humans"].astype(np.int64) + (env.n_static_host if hasattr(env, "n_static_host") else 0)
+            self._n_valid = torch.tensor(nv, device=dev)
+            self._v_pref = float(st["robot"][0, 7])
+            self._radius = torch.tensor(st["robot"][:, 4], device=dev)
+        env.lookahead_device(self._acts, self._bufs, human_policy=human_policy)
+        n_valid = self._n_valid if int(self._n_valid.min()) < env.R else None
+        values = self.values_from(self._bufs["rows_rotated"], self._bufs["reward"], n_valid,
+                                  env.params.time_step, self._v_pref)
+        best = torch.argmax(values, dim=1)
+        return self._acts[best], values

@@ -624,9 +624,61 @@ def gen_known_answers(ref):
         json.dump(table, f, indent=1)
 
 
+# ------------------------------------------------- (ix) SARL decisions (look-ahead + value net)
+SARL_RUNS = [
+    ("sarl_a5_baseline", A5, None, P1, "model_weights/sarl_model_baseline.pth", 2),
+    ("sarl_n10_ebcadrl", BIG, N10, "data/eb-cadrl/policy_x2_agent_type.config",
+     "data/eb-cadrl/rl_model_val.pth", 1),
+]
+
+
+def gen_sarl(ref):
+    """tests/test_basic_simulation.py:10-23 with rvo2 substituted: the reference's SARL policy
+    drives the robot; per decision the 81 action values and the chosen action are recorded."""
+    import shutil
+    import torch
+    from simulator.utils.test_utils import configure_env_policy_robot
+    os.makedirs(os.path.join(HERE, "weights"), exist_ok=True)
+    RVO2_MODE["substitute"] = True
+    for name, env_path, overrides, pol_path, weights, case in SARL_RUNS:
+        text = cfg_text(os.path.join(ref, env_path), overrides)
+        cfg = parsed(text)
+        tmp = write_tmp(text)
+        try:
+            env, pol, robot = configure_env_policy_robot(tmp, os.path.join(ref, pol_path),
+                                                         os.path.join(ref, weights))
+        finally:
+            os.unlink(tmp)
+        wname = name + ".pth"
+        shutil.copy(os.path.join(ref, weights), os.path.join(HERE, "weights", wname))  # data fixture
+        ob, _ = env.reset("test", test_case=case, compute_local_map=False)
+        init = scene_arrays(env)
+        acts, vals, infos, rewards = [], [], [], []
+        done = False
+        while not done and len(acts) < 200:
+            action = robot.act(ob, env=env)
+            acts.append([action[0], action[1]])
+            vals.append(list(pol.action_values) if pol.action_values else [float("nan")] * 81)
+            ob, _, reward, done, info = env.step(action, compute_local_map=False)
+            infos.append(info_code(info))
+            rewards.append(reward)
+        params = ebc_config.params_from_config(cfg, parsed(open(os.path.join(ref, pol_path)).read()))
+        out = {("init_" + k): v for k, v in init.items()}
+        out.update(action=np.array(acts), values=np.array(vals), info=np.array(infos),
+                   reward=np.array(rewards, float),
+                   action_space=np.array([[a[0], a[1]] for a in pol.action_space]),
+                   params=jdump(ebc_config.params_to_dict(params)),
+                   meta=jdump({"config": env_path, "policy_config": pol_path, "weights": wname,
+                               "gamma": pol.gamma, "seed_case": case, "final_info": infos[-1],
+                               "with_global_state": True}))
+        save(name, **out)
+        print("  %s: %d decisions, final info code %d" % (name, len(acts), infos[-1]))
+    RVO2_MODE["substitute"] = False
+
+
 GENERATORS = {"collisions": gen_collisions, "reward": gen_reward, "grid": gen_grid,
               "rotate": gen_rotate, "action_space": gen_action_space, "scenes": gen_scenes,
-              "trajectories": gen_trajectories, "known": gen_known_answers}
+              "trajectories": gen_trajectories, "known": gen_known_answers, "sarl": gen_sarl}
 
 
 def main():
