@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one ebc_step launch over the rank's scene batch: ORCA for every human,
+A "step" is one ebc_step call (phase 1 + phase 2 launches) over the rank's scene batch: ORCA for every human,
 kinematics, swept collisions, grid window, reward, rotated observation — inputs resident in
 HBM, outputs left in HBM.  Scenes are independent, so ranks own disjoint env slices and the
 data path has no collective (weak scaling: per-GPU batch fixed); torch.distributed (RCCL) only
@@ -175,7 +175,7 @@ def main():
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d envs/GPU x %d humans + %d static rows, ORCA + kinematics + "
-                                   "collisions + reward + rotated obs (T=%d) in one HIP launch per step, "
+                                   "collisions + reward + rotated obs (T=%d), one ebc_step (two HIP launches) per step, "
                                    "auto-reset%s" % (args.workload, E, batch.N, batch.S, env.T,
                                                    "" if hp == _abi.HUMAN_ORCA else " [DIAGNOSTIC: linear humans]"),
                        "envs_per_gpu": E, "humans": int(batch.N), "parallelism": "env-slice x%d" % world},
