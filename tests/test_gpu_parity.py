@@ -265,3 +265,102 @@ def test_device_resident_step_matches_host_step():
         torch.cuda.synchronize()
         for k in outs:
             np.testing.assert_array_equal(outs[k].cpu().numpy(), h[k], err_msg=k)
+
+
+def _synthetic_batch(rs, E, N, S, n_lo=0, walls=True):
+    """Random scenes built directly as SoA (no generator): ragged humans incl. empty envs,
+    random static rows and a few occupied grid cells."""
+    n = rs.randint(n_lo, N + 1, size=E).astype(np.int32)
+    f = lambda *s: np.zeros(s)  # noqa: E731
+    b = ebc_scene.SceneBatch(E, N, S, n, f(E, N), f(E, N), f(E, N), f(E, N), f(E, N), f(E, N),
+                             f(E, N), f(E, N), np.zeros((E, N), np.uint8),
+                             rs.randint(0, S + 1, size=E).astype(np.int32) if S else np.zeros(E, np.int32),
+                             f(E, max(S, 1)), f(E, max(S, 1)), f(E, max(S, 1)), None, f(E, 9))
+    for e in range(E):
+        k = n[e]
+        b.px[e, :k] = rs.uniform(-4, 4, k); b.py[e, :k] = rs.uniform(-4, 4, k)
+        b.vx[e, :k] = rs.uniform(-0.5, 0.5, k); b.vy[e, :k] = rs.uniform(-0.5, 0.5, k)
+        b.gx[e, :k] = rs.uniform(-4, 4, k); b.gy[e, :k] = rs.uniform(-4, 4, k)
+        b.radius[e, :k] = rs.uniform(0.1, 0.5, k); b.v_pref[e, :k] = rs.uniform(0.3, 1.2, k)
+        b.type[e, :k] = np.sort(rs.randint(0, 3, k))
+        m = b.n_static[e]
+        b.spx[e, :m] = rs.uniform(-4, 4, m); b.spy[e, :m] = rs.uniform(-4, 4, m)
+        b.sradius[e, :m] = rs.uniform(0.3, 0.8, m)
+        b.robot[e] = [rs.uniform(-1, 1), -3.0, 0, 0, 0.3, 0.0, 3.0, 0.7, np.pi / 2]
+    if walls:
+        grid = np.ones((E, 90, 90))
+        for e in range(E):
+            for _ in range(3):
+                x, y = rs.randint(5, 80, 2)
+                grid[e, x:x + rs.randint(1, 12), y:y + rs.randint(1, 12)] = 0
+        b.grid = np.stack([ebc_scene.pack_grid(g) for g in grid])
+    return b
+
+
+EDGE = [
+    # name, N, S, params overrides, robot kinematics, border
+    ("empty-and-ragged-N7", 7, 3, {}, "holonomic", None),
+    ("single-human", 1, 0, {}, "holonomic", None),
+    ("visible-robot", 6, 2, {"robot_visible": 1}, "holonomic", None),
+    ("unicycle-rotation-penalty", 5, 0, {"rotation_penalty_factor": -0.004}, "unicycle", None),
+    ("border", 5, 2, {}, "holonomic", [-3.5, 3.5, -3.2, 3.4]),
+    ("group-of-32-N24", 24, 6, {}, "holonomic", None),
+    ("visible-robot-N33-others", 32, 0, {"robot_visible": 1}, "holonomic", None),
+]
+
+
+@pytest.mark.parametrize("name,N,S,over,kin,border", EDGE)
+def test_edge_cases_vs_oracle(name, N, S, over, kin, border):
+    from oracle import oracle
+    params = params_of(load("traj_n10_walls_t17_orcasub"))
+    for k, v in over.items():
+        setattr(params, k, v)
+    params.robot_kinematics = _abi.HOLONOMIC if kin == "holonomic" else _abi.UNICYCLE
+    params.rotate_unicycle = int(kin == "unicycle")
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) % 2 ** 31)
+    E = 70
+    b = _synthetic_batch(rs, E, N, S)
+    g = _env(params, E, N, S)
+    o = oracle.OracleEnv(params, E, N, S)
+    g.reset(b)
+    o.reset(b)
+    if kin == "holonomic":
+        space = ebc_actions.build_action_space(0.7)
+    else:
+        space = ebc_actions.build_action_space(0.7, "unicycle")
+    for t in range(25):
+        act = space[rs.randint(len(space), size=E)]
+        if t % 6 == 0:
+            lg = g.lookahead(space, human_policy=_abi.HUMAN_ORCA, border=border)
+            lo = o.lookahead(space, human_policy=_abi.HUMAN_ORCA, border=border)
+            np.testing.assert_array_equal(lg["info"], lo["info"])
+            np.testing.assert_allclose(lg["reward"], lo["reward"], atol=1e-9)
+            np.testing.assert_allclose(lg["rows_rotated"], lo["rows_rotated"], atol=1e-5, rtol=1e-5)
+        _compare_step(g.step(robot_action=act, human_policy=_abi.HUMAN_ORCA, border=border,
+                             flags=_abi.FLAG_AUTO_RESET),
+                      o.step(robot_action=act, human_policy=_abi.HUMAN_ORCA, border=border,
+                             flags=_abi.FLAG_AUTO_RESET), "%s step %d" % (name, t))
+    sg, so = g.get_state(), o.get_state()
+    for k in sg:
+        np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
+
+
+def test_maximum_actions_and_rows():
+    """128 actions x (33 + 95 = 128) rows: the limits ebc_create / ebc_lookahead accept."""
+    from oracle import oracle
+    params = params_of(load("traj_a5_linear_orcasub"))
+    rs = np.random.RandomState(5)
+    E, N, S = 6, 33, 95
+    b = _synthetic_batch(rs, E, N, S, n_lo=30, walls=False)
+    g = _env(params, E, N, S)
+    o = oracle.OracleEnv(params, E, N, S)
+    g.reset(b)
+    o.reset(b)
+    space = rs.uniform(-0.7, 0.7, size=(128, 2))
+    lg = g.lookahead(space, human_policy=_abi.HUMAN_ORCA)
+    lo = o.lookahead(space, human_policy=_abi.HUMAN_ORCA)
+    np.testing.assert_array_equal(lg["info"], lo["info"])
+    np.testing.assert_allclose(lg["rows_rotated"], lo["rows_rotated"], atol=1e-5, rtol=1e-5)
+    _compare_step(g.step(robot_action=space[:E], human_policy=_abi.HUMAN_CACHED),
+                  o.step(robot_action=space[:E], human_policy=_abi.HUMAN_ORCA), "max sizes")
