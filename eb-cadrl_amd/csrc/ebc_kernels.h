@@ -628,6 +628,48 @@ __global__ __launch_bounds__(EBC_WAVE) void phase2_kernel(EbcParams p_in, DevSta
   service_commit<T>(p, s, io, m, h, pre, A, rbn, io.auto_reset && done_flag, gtime + p.time_step, ax, ay);
 }
 
+// ------------------------------------------------------------------------- observe
+// Rows of the current state (env.py:188-193), raw and rotated; thread = (env, row).
+template <int T>
+__global__ __launch_bounds__(256) void observe_kernel(EbcParams p, DevState s, double *ob, float *obs) {
+  const int R = s.N + s.S;
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= (size_t)s.E * R) return;
+  const size_t e = g / R;
+  const int r = (int)(g - e * R);
+  const int n = s.n_humans[e];
+  const int ns = s.S ? s.n_static[e] : 0;
+  double opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
+  int otype = 0;
+  bool valid = false;
+  if (r < n) {
+    const size_t k = e * s.N + r;
+    opx = s.px[k]; opy = s.py[k]; ovx = s.vx[k]; ovy = s.vy[k]; orad = s.radius[k]; otype = s.type[k];
+    valid = true;
+  } else if (r - n < ns) {
+    const size_t q = e * s.S + (r - n);
+    opx = s.spx[q]; opy = s.spy[q]; orad = s.sradius[q]; otype = EBC_ADULT_STATIC;
+    valid = true;
+  }
+  if (ob) {
+    double *o = ob + g * 5;
+    o[0] = opx; o[1] = opy; o[2] = ovx; o[3] = ovy; o[4] = orad;
+  }
+  if (obs) {
+    float out[T];
+    if (valid) {
+      const RotFrame f = rot_frame(s.robot + e * 9, p.rotate_unicycle);
+      rotate_row<T>(f, opx, opy, ovx, ovy, orad, otype, out);
+    } else {
+#pragma unroll
+      for (int c = 0; c < T; ++c) out[c] = 0.0f;
+    }
+    float *o = obs + g * T;
+#pragma unroll
+    for (int c = 0; c < T; ++c) o[c] = out[c];
+  }
+}
+
 // ------------------------------------------------------------------------- look-ahead
 // The |A|-way onestep_lookahead sweep of MultiHumanRL.predict (multi_human_rl.py:38-61), one
 // 256-thread workgroup per env.  Human velocities come from s.hact (ORCA kernel,

@@ -480,6 +480,31 @@ int ebc_step(void *handle, const EbcStepArgs *a) {
   return EBC_OK;
 }
 
+int ebc_observe(void *handle, int location, double *ob, float *obs_rotated) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_observe before ebc_reset");
+  const DevState &s = h->s;
+  const size_t rows = (size_t)s.E * (s.N + s.S), T = h->T;
+  double *d_ob = ob;
+  float *d_obs = obs_rotated;
+  Stager st{h};
+  if (location != EBC_DEVICE) {
+    if ((rc = ensure_stage(h, pad256(rows * 5 * 8) + pad256(rows * T * 4) + 1024)) != EBC_OK) return rc;
+    d_ob = st.out(ob, rows * 5);
+    d_obs = st.out(obs_rotated, rows * T);
+  }
+  const unsigned blocks = (unsigned)((rows + 255) / 256);
+  if (h->T == 17)
+    hipLaunchKernelGGL((ebc::observe_kernel<17>), dim3(blocks), dim3(256), 0, h->stream, h->p, h->s, d_ob, d_obs);
+  else
+    hipLaunchKernelGGL((ebc::observe_kernel<13>), dim3(blocks), dim3(256), 0, h->stream, h->p, h->s, d_ob, d_obs);
+  HIP_TRY(hipGetLastError());
+  if (location != EBC_DEVICE) return st.finish();
+  return EBC_OK;
+}
+
 int ebc_lookahead(void *handle, const EbcLookaheadArgs *a) {
   Handle *h;
   int rc = check_handle(handle, &h);

@@ -21,6 +21,7 @@ SYMBOLS = {
     "ebc_synchronize": (C.c_int, [C.c_void_p]),
     "ebc_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ebc_set_human_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ebc_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ebc_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_lookahead": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),

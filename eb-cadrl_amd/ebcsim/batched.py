@@ -138,6 +138,17 @@ class BatchedEnv:
         _capi.check(self._L.ebc_lookahead(self._h, C.addressof(args)))
         return out
 
+    def observe(self):
+        """(ob [E, R, 5], obs_rotated [E, R, T]) of the current state (what reset() returns)."""
+        ob = np.zeros((self.E, self.R, 5))
+        obs = np.zeros((self.E, self.R, self.T), np.float32)
+        _capi.check(self._L.ebc_observe(self._h, _abi.HOST, ob.ctypes.data, obs.ctypes.data))
+        return ob, obs
+
+    def observe_device(self, obs_rotated):
+        """Rotated observation of the current state into a torch CUDA tensor [E, R, T]."""
+        _capi.check(self._L.ebc_observe(self._h, _abi.DEVICE, None, obs_rotated.data_ptr()))
+
     def get_state(self):
         E, N = self.E, self.N
         f = lambda *s: np.zeros(s)  # noqa: E731

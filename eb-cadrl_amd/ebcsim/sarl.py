@@ -41,9 +41,12 @@ class SarlValueNet(object):
     def load(cls, path, device="cpu", **kw):
         return cls(torch.load(path, map_location="cpu"), device=device, **kw)
 
-    @torch.no_grad()
     def forward(self, rows, n_valid=None):
         """rows [B, R, T] float32; n_valid [B] (rows that exist) or None = all -> values [B]."""
+        with torch.no_grad():
+            return self._forward(rows, n_valid)
+
+    def _forward(self, rows, n_valid=None):
         B, R, T = rows.shape
         self_state = rows[:, 0, :self.self_state_dim]
         h1 = _mlp(rows.reshape(B * R, T), self.mlp1, True)

@@ -221,6 +221,11 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *scene);
 /* Humans moved by the host (BASELINE config 2): act[E][N][2]. */
 int ebc_set_human_actions(void *handle, int location, const double *act);
 
+/* The observation of the CURRENT state, without stepping: what env.reset returns
+ * (simulator/env.py:188-193) and what MultiHumanRL.transform builds from it
+ * (rl/policy/multi_human_rl.py:128-149).  ob [E][R][5], obs_rotated [E][R][T]; either may be NULL. */
+int ebc_observe(void *handle, int location, double *ob, float *obs_rotated);
+
 int ebc_step(void *handle, const EbcStepArgs *args);
 int ebc_lookahead(void *handle, const EbcLookaheadArgs *args);
 int ebc_get_state(void *handle, const EbcStateView *view);

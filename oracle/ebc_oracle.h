@@ -78,6 +78,7 @@ void orc_rotate_row(const double in[15], int with_agent_type, int rotate_unicycl
 void orc_propagate_robot(const double *robot, int kinematics, double a0, double a1, double dt,
                          double next[9]);
 
+int orc_observe(const EbcParams *p, const OrcState *s, double *ob, float *obs_rotated);
 int orc_step(const EbcParams *p, OrcState *s, const EbcStepArgs *a);
 int orc_lookahead(const EbcParams *p, OrcState *s, const EbcLookaheadArgs *a);
 

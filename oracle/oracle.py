@@ -55,6 +55,8 @@ def lib():
         L.orc_rotate_row.argtypes = [C.c_void_p, i, i, C.c_void_p]
         L.orc_propagate_robot.restype = None
         L.orc_propagate_robot.argtypes = [C.c_void_p, i, d, d, d, C.c_void_p]
+        L.orc_observe.restype = i
+        L.orc_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_step.restype = i
         L.orc_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lookahead.restype = i
@@ -267,6 +269,13 @@ class OracleEnv:
         if rc != 0:
             raise RuntimeError("orc_lookahead failed: %d" % rc)
         return out
+
+    def observe(self):
+        ob = np.zeros((self.E, self.R, 5))
+        obs = np.zeros((self.E, self.R, self.T), np.float32)
+        lib().orc_observe(C.addressof(self.params), C.addressof(self._state()), ob.ctypes.data,
+                          obs.ctypes.data)
+        return ob, obs
 
     def get_state(self):
         keys = ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type", "n_humans",

@@ -364,3 +364,30 @@ def test_maximum_actions_and_rows():
     np.testing.assert_allclose(lg["rows_rotated"], lo["rows_rotated"], atol=1e-5, rtol=1e-5)
     _compare_step(g.step(robot_action=space[:E], human_policy=_abi.HUMAN_CACHED),
                   o.step(robot_action=space[:E], human_policy=_abi.HUMAN_ORCA), "max sizes")
+
+
+def test_observe_is_the_returned_observation():
+    """ebc_observe of the current state = the ob / rotated rows the last step returned, and =
+    the oracle's; right after reset it is env.reset()'s observation."""
+    from oracle import oracle
+    z = load("traj_n10_walls_t17_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    E = 33
+    b, _ = _random_batch(_config_text(meta), [15000 + e for e in range(E)])
+    g = _env(params, E, b.N, b.S)
+    o = oracle.OracleEnv(params, E, b.N, b.S)
+    g.reset(b)
+    o.reset(b)
+    ob_g, obs_g = g.observe()
+    ob_o, obs_o = o.observe()
+    np.testing.assert_array_equal(ob_g, ob_o)
+    np.testing.assert_allclose(obs_g, obs_o, atol=1e-5, rtol=1e-5)
+    np.testing.assert_array_equal(ob_g[:, :b.N, 0], b.px)
+    for t in range(5):
+        out = g.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR)
+        o.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR)
+        ob_g, obs_g = g.observe()
+        np.testing.assert_array_equal(ob_g, out["ob"])
+        np.testing.assert_array_equal(obs_g, out["obs_rotated"])
+        np.testing.assert_allclose(obs_g, o.observe()[1], atol=1e-5, rtol=1e-5)

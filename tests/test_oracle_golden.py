@@ -170,3 +170,18 @@ def test_known_answer_scenes():
         z = load("known_" + row["scene"].replace(".json", "") + "_orcasub")
         env.reset(b)
         check_trajectory(env, z, atol=1e-12)
+
+
+def test_observe_matches_step_outputs():
+    z = load("traj_n10_walls_t17")
+    b = batch_from_init(z)
+    env = oracle.OracleEnv(params_of(z), 1, b.N, b.S)
+    env.reset(b)
+    ob, obs = env.observe()
+    n = len(z["init_px"])
+    np.testing.assert_array_equal(ob[0, :n, 0], z["init_px"])
+    out = env.step(robot_action=z["action"][0][None], human_policy=_abi.HUMAN_LINEAR)
+    ob, obs = env.observe()
+    np.testing.assert_array_equal(ob, out["ob"])
+    np.testing.assert_array_equal(obs, out["obs_rotated"])
+    np.testing.assert_allclose(obs[0, :len(z["rot"][0])], z["rot"][0], atol=1e-5, rtol=1e-5)

@@ -1,0 +1,128 @@
+"""BASELINE config 5 on CPU: two gloo ranks, each with its own replay shard, one flat-bucket
+gradient all-reduce per step -> the same parameters as one process on the union batch; value
+targets follow Explorer.update_memory; state_dicts are interchangeable with the reference's."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "eb-cadrl_amd")
+DIMS = dict(input_dim=13, mlp1_dims=[150, 100], mlp2_dims=[100, 50], mlp3_dims=[150, 100, 100, 1],
+            attention_dims=[100, 100, 1])
+
+
+def _data(seed, n, R=5, T=13):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, R, T, generator=g), torch.randn(n, generator=g)
+
+
+def _worker(rank, world, port, ret):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from ebcsim.train import DataParallelTrainer, DeviceReplay, SarlModule
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = SarlModule(**DIMS)
+    x, y = _data(100 + rank, 32)
+    mem = DeviceReplay(32, 5, 13, "cpu")
+    mem.push(x, y)
+
+    class All(object):  # deterministic "sample": the whole shard
+        def sample(self, bs, generator=None):
+            return mem.states, mem.values
+    tr = DataParallelTrainer(model, All(), 32, "sgd", 0.01)
+    for _ in range(3):
+        tr.optimize_batch(1)
+    if rank == 0:
+        ret["params"] = {k: v.detach().clone() for k, v in model.named_parameters()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_equals_single_process():
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from ebcsim.train import DataParallelTrainer, SarlModule
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, 29700 + os.getpid() % 1000, ret), nprocs=2, join=True)
+    torch.manual_seed(0)
+    model = SarlModule(**DIMS)
+    xs, ys = zip(_data(100, 32), _data(101, 32))
+    X, Y = torch.cat(xs), torch.cat(ys)
+
+    class All(object):
+        def sample(self, bs, generator=None):
+            return X, Y
+    tr = DataParallelTrainer(model, All(), 64, "sgd", 0.01)
+    for _ in range(3):
+        tr.optimize_batch(1)
+    for k, v in model.named_parameters():
+        torch.testing.assert_close(ret["params"][k], v.detach(), atol=2e-6, rtol=1e-5)
+
+
+def test_state_dict_roundtrip_and_value_targets():
+    from helpers import GOLDEN
+    from ebcsim.sarl import SarlValueNet
+    from ebcsim.train import DeviceReplay, SarlModule, value_targets
+    sd = torch.load(os.path.join(GOLDEN, "weights", "sarl_a5_baseline.pth"), map_location="cpu")
+    m = SarlModule(**DIMS)
+    m.load_reference_state_dict(sd)
+    back = m.reference_state_dict()
+    assert set(back) == set(sd)
+    for k in sd:
+        assert torch.equal(back[k], sd[k])
+    rows = torch.randn(7, 5, 13)
+    net = SarlValueNet(sd)
+    torch.testing.assert_close(m(rows), net.forward(rows))
+    # explorer.py:171-184
+    reward = torch.tensor([0.1, -0.25, 1.0], dtype=torch.float64)
+    done = torch.tensor([0, 1, 1], dtype=torch.uint8)
+    nxt = torch.randn(3, 5, 13)
+    t = value_targets(reward, done, nxt, net, 0.9)
+    v = net.forward(nxt).double()
+    torch.testing.assert_close(t, torch.stack([reward[0] + 0.9 * v[0], reward[1], reward[2]]))
+    mem = DeviceReplay(4, 5, 13, "cpu")
+    mem.push(torch.randn(3, 5, 13), torch.arange(3.0))
+    mem.push(torch.randn(3, 5, 13), torch.arange(3.0) + 10)   # wraps: capacity 4
+    assert len(mem) == 4 and mem.position == 2
+    assert sorted(mem.values.tolist()) == [2.0, 10.0, 11.0, 12.0]
+
+
+@pytest.mark.gpu
+def test_collect_and_train_on_device():
+    """Roll out on the HIP env with the device SARL policy, fill the replay, take optimizer
+    steps: the loss is finite and decreases on the fixed replay."""
+    import json
+    from helpers import GOLDEN, batch_from_init, load, params_of
+    from ebcsim.batched import BatchedEnv
+    from ebcsim.sarl import DeviceSarlPolicy
+    from ebcsim.train import DataParallelTrainer, DeviceReplay, SarlModule, collect
+    z = load("sarl_a5_baseline")
+    meta = json.loads(str(z["meta"]))
+    E = 64
+    b = batch_from_init(z, copies=E)
+    env = BatchedEnv(params_of(z), E, b.N, b.S)
+    env.reset(b)
+    env.use_torch_stream()
+    model = SarlModule(**DIMS).to("cuda:0")
+    model.load_reference_state_dict(torch.load(os.path.join(GOLDEN, "weights", meta["weights"]), map_location="cpu"))
+    target = SarlModule(**DIMS).to("cuda:0")
+    target.load_state_dict(model.state_dict())
+    pol = DeviceSarlPolicy(model.as_value_net(), z["action_space"], meta["gamma"])
+    mem = DeviceReplay(4096, env.R, env.T, "cuda:0")
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    mean_r = collect(env, pol, target.as_value_net(), mem, 30, meta["gamma"], epsilon=0.2, generator=g)
+    assert len(mem) == 30 * E and np.isfinite(mean_r)
+    tr = DataParallelTrainer(model, mem, 100, "sgd", 0.001)
+    first = tr.optimize_batch(20, g)
+    last = tr.optimize_batch(20, g)
+    assert np.isfinite(first) and np.isfinite(last) and last < first * 1.5
