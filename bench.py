@@ -112,10 +112,17 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    # one process per GPU; EBCSIM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer
+    # GPUs than ranks (ranks then share devices; timing is meaningless, the code path is not)
+    backend = os.environ.get("EBCSIM_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ebcsim import _abi
     from ebcsim.batched import BatchedEnv
@@ -157,7 +164,8 @@ def main():
     env.timing(False)
 
     from ebcsim import shard
-    elapsed_max, total_humans = shard.job_rate(elapsed, float(batch.n_humans.sum()), device=dev)
+    elapsed_max, total_humans = shard.job_rate(elapsed, float(batch.n_humans.sum()),
+                                              device=dev if backend == "nccl" else None)
 
     if rank == 0:
         S_mean = float(batch.n_static.mean()) if batch.S else 0.0

@@ -186,19 +186,34 @@ class BatchedEnv:
 
     def step_device(self, outputs, robot_action=None, human_policy=_abi.HUMAN_ORCA,
                     robot_policy=_abi.ROBOT_EXTERNAL, flags=0):
-        """Enqueue one step; `outputs`/`robot_action` are torch CUDA tensors (not copied)."""
-        args = _abi.EbcStepArgs()
-        args.struct_size = C.sizeof(args)
-        args.location = _abi.DEVICE
-        args.human_policy, args.robot_policy = int(human_policy), int(robot_policy)
-        args.flags = int(flags)
-        if robot_action is not None:
-            if robot_action.dtype.itemsize != 8 or robot_action.numel() != self.E * 2:
-                raise ValueError("robot_action must be float64 [E, 2]")
-            args.robot_action = robot_action.data_ptr()
-        for k, t in outputs.items():
-            setattr(args, k, t.data_ptr())
-        _capi.check(self._L.ebc_step(self._h, C.addressof(args)))
+        """Enqueue one step; `outputs`/`robot_action` are torch CUDA tensors (not copied).  The
+        argument block is cached per (tensor addresses, policies, flags): a training loop that
+        re-uses its buffers pays one ctypes call per step."""
+        key = (tuple((k, t.data_ptr()) for k, t in outputs.items()),
+               None if robot_action is None else robot_action.data_ptr(),
+               int(human_policy), int(robot_policy), int(flags))
+        cache = self.__dict__.setdefault("_step_args", {})
+        args = cache.get(key)
+        if args is None:
+            args = _abi.EbcStepArgs()
+            args.struct_size = C.sizeof(args)
+            args.location = _abi.DEVICE
+            args.human_policy, args.robot_policy = int(human_policy), int(robot_policy)
+            args.flags = int(flags)
+            if robot_action is not None:
+                if robot_action.dtype.itemsize != 8 or robot_action.numel() != self.E * 2:
+                    raise ValueError("robot_action must be float64 [E, 2]")
+                if not robot_action.is_contiguous():
+                    raise ValueError("robot_action must be contiguous")
+                args.robot_action = robot_action.data_ptr()
+            for k, t in outputs.items():
+                setattr(args, k, t.data_ptr())
+            if len(cache) > 64:
+                cache.clear()
+            cache[key] = args
+        rc = self._L.ebc_step(self._h, C.addressof(args))
+        if rc:
+            _capi.check(rc)
 
     def alloc_lookahead_outputs(self, n_actions, keys=("reward", "done", "info", "rows_rotated")):
         """torch CUDA tensors for lookahead_device(); the caller owns them."""
