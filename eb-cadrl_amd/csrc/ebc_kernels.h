@@ -148,7 +148,7 @@ __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s,
   }
   orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy,
                  ovx, ovy, orad, dist_lds + group * GS, lines_lds + group * GS, proj_lds + group * GS,
-                 ox, oy);
+                 N - 1 + (p.robot_visible ? 1 : 0), ox, oy);
 }
 
 // ORCA alone -> s.hact: the prelude of a look-ahead sweep (the following step re-uses it).

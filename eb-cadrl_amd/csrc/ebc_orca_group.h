@@ -28,30 +28,35 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // ---- group collectives (all lanes of the group are active together) -----------------------
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-#define EBC_DPP_XOR1 0xB1         // quad_perm [1,0,3,2]
-#define EBC_DPP_XOR2 0x4E         // quad_perm [2,3,0,1]
-#define EBC_DPP_HALF_MIRROR 0x141 // lane i <-> 7 - i  within 8
-#define EBC_DPP_MIRROR 0x140      // lane i <-> 15 - i within 16
+// min / max all-reduce over the group with DPP row operations fused into the arithmetic
+// instruction (v_min_f32_dpp: dst = min(permuted src0, src1)).  Written as asm because the
+// builtin route costs a v_mov_b32_dpp, two canonicalising v_max and the min per step; the
+// "s_nop 1" is the two wait states a DPP read needs after the VALU write of its source
+// (hipcc does not insert hazards inside asm).  quad_perm [1,0,3,2] / [2,3,0,1] exchange within
+// 4 lanes, row_half_mirror within 8, row_mirror within 16; 32-lane groups add one shuffle.
+#define EBC_DPP_STEP(op, ctrl)                                                                     \
+  asm volatile("s_nop 1\n\t" op " %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1"   \
+               : "=v"(r)                                                                           \
+               : "v"(v));                                                                          \
+  v = r;
 
 template <int GS>
 __device__ __forceinline__ float group_min(float v) {
-  v = fminf(v, dpp_f<EBC_DPP_XOR1>(v));
-  v = fminf(v, dpp_f<EBC_DPP_XOR2>(v));
-  v = fminf(v, dpp_f<EBC_DPP_HALF_MIRROR>(v));
-  if (GS >= 16) v = fminf(v, dpp_f<EBC_DPP_MIRROR>(v));
+  float r;
+  EBC_DPP_STEP("v_min_f32_dpp", "quad_perm:[1,0,3,2]")
+  EBC_DPP_STEP("v_min_f32_dpp", "quad_perm:[2,3,0,1]")
+  EBC_DPP_STEP("v_min_f32_dpp", "row_half_mirror")
+  if (GS >= 16) { EBC_DPP_STEP("v_min_f32_dpp", "row_mirror") }
   if (GS >= 32) v = fminf(v, __shfl_xor(v, 16, 64));
   return v;
 }
 template <int GS>
 __device__ __forceinline__ float group_max(float v) {
-  v = fmaxf(v, dpp_f<EBC_DPP_XOR1>(v));
-  v = fmaxf(v, dpp_f<EBC_DPP_XOR2>(v));
-  v = fmaxf(v, dpp_f<EBC_DPP_HALF_MIRROR>(v));
-  if (GS >= 16) v = fmaxf(v, dpp_f<EBC_DPP_MIRROR>(v));
+  float r;
+  EBC_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2]")
+  EBC_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1]")
+  EBC_DPP_STEP("v_max_f32_dpp", "row_half_mirror")
+  if (GS >= 16) { EBC_DPP_STEP("v_max_f32_dpp", "row_mirror") }
   if (GS >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
   return v;
 }
@@ -152,7 +157,7 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
                                            float radius, float maxSpeed, float prefx, float prefy,
                                            float opx, float opy, float ovx, float ovy, float orad,
                                            float *dist_lds, float4 *lines_lds, float4 *proj_lds,
-                                           float &out_x, float &out_y) {
+                                           int max_others, float &out_x, float &out_y) {
   const float rangeSq = p.orca_neighbor_dist * p.orca_neighbor_dist;
   const float invTimeHorizon = 1.0f / p.orca_time_horizon;
   const float timeStep = (float)p.time_step;
@@ -168,12 +173,14 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
   int rank = 0;
 #pragma unroll
   for (int k4 = 0; k4 < GS / 4; ++k4) {
-    const float4 d4 = reinterpret_cast<const float4 *>(dist_lds)[k4];
-    const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+    if (k4 * 4 < max_others) {  // kernel-uniform: slots past N - 1 (+ robot) never hold an other
+      const float4 d4 = reinterpret_cast<const float4 *>(dist_lds)[k4];
+      const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int k = k4 * 4 + c;
-      rank += (dv[c] < distSqN || (dv[c] == distSqN && k < j)) ? 1 : 0;
+      for (int c = 0; c < 4; ++c) {
+        const int k = k4 * 4 + c;
+        rank += (dv[c] < distSqN || (dv[c] == distSqN && k < j)) ? 1 : 0;
+      }
     }
   }
   const bool included = inRange && rank < maxN;

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void k(EbcParams p, Tile t) {
   float ox = prefx, oy = prefy;
   if (MODE == 0) {
     ebc::orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy,
-                        ovx, ovy, orad, dist_lds + group * GS, lines_lds + group * GS, proj_lds + group * GS, ox, oy);
+                        ovx, ovy, orad, dist_lds + group * GS, lines_lds + group * GS, proj_lds + group * GS, N - 1, ox, oy);
   } else if (MODE == 3) {
     ox = posx + opx + velx + vely + radius + maxSpeed + opy + ovx + ovy + orad;
   }
