@@ -75,6 +75,11 @@ class EntityBasedCollisionAvoidance(object):
         self.use_grid_map = config.getboolean("map", "use_grid_map")  # raises without [map], like env.py:79
         if self.use_grid_map:
             raise NotImplementedError("use_grid_map = true (cv2 local maps) is set by no shipped config")
+        self.angular_map_max_range = config.getfloat("map", "angular_map_max_range")
+        self.angular_map_dim = config.getint("map", "angular_map_dim")
+        self.angular_map_min_angle = config.getfloat("map", "angle_min") * np.pi
+        self.angular_map_max_angle = config.getfloat("map", "angle_max") * np.pi
+        self.local_maps_angular = None
         kinds = set()
         for section, count in (("adults", self._scene_cfg.adult_num),
                                ("bicycles", self._scene_cfg.bicycle_num),
@@ -105,6 +110,16 @@ class EntityBasedCollisionAvoidance(object):
             self._params = params
             self._backend_key = key
         return self._backend
+
+    def get_local_map_angular(self, ob, normalize=True, append=True):
+        """simulator/env.py:570-628, on the host (ebcsim/local_map.py): no policy on the path reads it."""
+        from .local_map import angular_map
+        m = angular_map(self.scene.obstacle_vertices, ob.px, ob.py, ob.radius, ob.theta,
+                        self.angular_map_max_range, self.angular_map_dim, self.angular_map_min_angle,
+                        self.angular_map_max_angle, normalize)
+        if append:
+            self.local_maps_angular.append(m)
+        return m
 
     # ---------------------------------------------------------------- reset
     def reset_times(self, phase):
@@ -168,12 +183,13 @@ class EntityBasedCollisionAvoidance(object):
         backend.reset(batch)
 
         self.states = list()
+        self.local_maps_angular = list()
         if hasattr(self.robot.policy, "action_values"):
             self.action_values = list()
         if hasattr(self.robot.policy, "get_attention_weights"):
             self.attention_weights = list()
         ob = [h.get_observable_state() for h in self._humans] + sc.static_obstacles_as_pedestrians
-        local_map = None  # angular local map: SURVEY 8(f)(3), no consumer on this path
+        local_map = self.get_local_map_angular(self.robot.get_full_state()) if compute_local_map else None
         if self.robot.policy is not None and self.robot.policy.name == "ORCA":
             return ob, sc.obstacle_vertices, local_map
         return ob, local_map
@@ -199,8 +215,8 @@ class EntityBasedCollisionAvoidance(object):
         return ebc_info.from_code(code, dist_to_goal, dmin, list(self._params.discomfort_dist))
 
     def onestep_lookahead(self, action):
-        """simulator/env.py:207-209"""
-        ob, _, reward, done, info = self.step(action, update=False)
+        """simulator/env.py:207-209 (the reference also recomputes the local map here and drops it)"""
+        ob, _, reward, done, info = self.step(action, update=False, compute_local_map=False)
         return ob, reward, done, info
 
     def lookahead_all(self, actions):
@@ -221,7 +237,9 @@ class EntityBasedCollisionAvoidance(object):
             nx, ny = self.robot.compute_position(action, self.time_step)
             dg = float(np.linalg.norm(np.array((nx, ny)) - np.array(self.robot.get_goal_position())))
             info = self._info(out["info"][0, 0], dg, out["dmin"][0, 0])
-            return ob, None, float(out["reward"][0, 0]), bool(out["done"][0, 0]), info
+            # env.py:460-465: the map of the CURRENT robot state, also in look-ahead
+            local_map = self.get_local_map_angular(self.robot.get_full_state()) if compute_local_map else None
+            return ob, local_map, float(out["reward"][0, 0]), bool(out["done"][0, 0]), info
 
         # render history: full states before the update (env.py:344-351)
         sc = self.scene
@@ -250,7 +268,8 @@ class EntityBasedCollisionAvoidance(object):
             k += len(group)
         ob = self._rows_to_ob(out["ob"][0])
         info = self._info(out["info"][0], out["dist_to_goal"][0], out["dmin"][0])
-        return ob, None, float(out["reward"][0]), bool(out["done"][0]), info
+        local_map = self.get_local_map_angular(self.robot.get_full_state()) if compute_local_map else None
+        return ob, local_map, float(out["reward"][0]), bool(out["done"][0]), info
 
     def render(self, mode="adult", output_file=None):
         raise NotImplementedError("rendering (simulator/utils/render.py) is outside the accelerated "

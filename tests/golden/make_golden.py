@@ -676,9 +676,40 @@ def gen_sarl(ref):
     RVO2_MODE["substitute"] = False
 
 
+# ------------------------------------------------------------- (x) angular local map
+def gen_local_map(ref):
+    pol = os.path.join(ref, "configs/test_configs/test_policy_configs/policy.config")
+    rs = np.random.RandomState(21)
+    out = {}
+    k = 0
+    for path in ("configs/test_configs/test_env_configs/env_adults_3_bikes_3_static_2.config",
+                 "configs/test_configs/test_env_configs/env_adults_5_bikes_5_static_5.config",
+                 "configs/test_configs/test_env_configs/env_adults_3_bikes_3_static_20.config"):
+        env, _, robot = make_env(ref, cfg_text(os.path.join(ref, path)), pol)
+        for case in range(3):
+            env.reset("test", test_case=case, compute_local_map=False)
+            poses, maps = [], []
+            for _ in range(12):
+                robot.px, robot.py = rs.uniform(-4, 4), rs.uniform(-4, 4)
+                robot.theta = rs.uniform(-np.pi, np.pi)
+                robot.radius = [0.2, 0.3][_ % 2]
+                maps.append(env.get_local_map_angular(robot.get_full_state(), append=False))
+                poses.append([robot.px, robot.py, robot.radius, robot.theta])
+            out["pose_%d" % k] = np.array(poses)
+            out["map_%d" % k] = np.array(maps)
+            out["meta_%d" % k] = jdump({"vertices": [[list(map(float, p)) for p in poly]
+                                                     for poly in env.scene.obstacle_vertices],
+                                        "max_range": env.angular_map_max_range, "dim": env.angular_map_dim,
+                                        "angle_min": env.angular_map_min_angle,
+                                        "angle_max": env.angular_map_max_angle})
+            k += 1
+    out["n"] = np.array(k)
+    save("local_map", **out)
+
+
 GENERATORS = {"collisions": gen_collisions, "reward": gen_reward, "grid": gen_grid,
               "rotate": gen_rotate, "action_space": gen_action_space, "scenes": gen_scenes,
-              "trajectories": gen_trajectories, "known": gen_known_answers, "sarl": gen_sarl}
+              "trajectories": gen_trajectories, "known": gen_known_answers, "sarl": gen_sarl, "local_map": gen_local_map}
 
 
 def main():

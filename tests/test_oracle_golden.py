@@ -185,3 +185,16 @@ def test_observe_matches_step_outputs():
     np.testing.assert_array_equal(ob, out["ob"])
     np.testing.assert_array_equal(obs, out["obs_rotated"])
     np.testing.assert_allclose(obs[0, :len(z["rot"][0])], z["rot"][0], atol=1e-5, rtol=1e-5)
+
+
+def test_angular_local_map():
+    """simulator/env.py:468-628 restated on the host (ebcsim/local_map.py), bit-exact."""
+    from ebcsim.local_map import angular_map
+    z = load("local_map")
+    for k in range(int(z["n"])):
+        m = json.loads(str(z["meta_%d" % k]))
+        for pose, ref in zip(z["pose_%d" % k], z["map_%d" % k]):
+            got = angular_map(m["vertices"], pose[0], pose[1], pose[2], pose[3], m["max_range"],
+                              m["dim"], m["angle_min"], m["angle_max"])
+            np.testing.assert_array_equal(got, ref)
+    assert (z["map_0"] < 1).any()
