@@ -23,6 +23,24 @@
 
 namespace ebc {
 
+// Scenes an env restarts from under EBC_FLAG_AUTO_RESET, in the same SoA layout as the state.
+// Slots [0, E) are the envs' own ebc_reset scenes; slots [E, E + P) a host-generated pool installed
+// by ebc_set_scene_pool.  cursor[e] is the slot env e restarts from next: e itself without a pool
+// (stride 0), else it walks E + (e mod P), + stride, ... (mod P) from episode to episode without
+// leaving the device.  Occupancy grids are never copied: an env points at the grid of the slot it
+// is running (grid_scene[e]).
+struct ScenePool {
+  int P, stride;  // custom scenes (0 = none) and the cursor step
+  int *cursor;  // [E]
+  int *n_humans;
+  double *px, *py, *vx, *vy, *gx, *gy, *radius, *v_pref;
+  uint8_t *type;
+  int *n_static;
+  double *spx, *spy, *sradius;
+  uint64_t *grid;  // nullptr: free maps
+  double *robot;
+};
+
 struct DevState {
   int E, N, S, G;
   int *n_humans;
@@ -30,14 +48,14 @@ struct DevState {
   uint8_t *type;
   int *n_static;
   double *spx, *spy, *sradius;
-  uint64_t *grid;  // nullptr when every map is free
+  int *grid_scene;  // [E] pool slot whose occupancy grid env e uses (pool.grid is null when every map is free)
   double *robot;    // [E][9] FullState order
   double *robot_n;  // [E][9] scratch: next robot state between phase 1 and phase 2
   double *time;   // [E] global_time
   double *arrival;
   uint8_t *done;  // terminal flag of the last step
   double *hact;   // [E][N][2] human velocities: ORCA role, ebc_set_human_actions, or look-ahead cache
-  double *px0, *py0, *vx0, *vy0, *robot0;  // reset() copies for auto-reset
+  ScenePool pool;  // where auto-reset takes an env's next scene from
   // what rvo2 would hold for the current state (float): position, velocity,
   // radius + 0.01 + safety, maxSpeed, preferred velocity
   float *fpx, *fpy, *fvx, *fvy, *frad, *fmax, *fprefx, *fprefy;
@@ -256,22 +274,16 @@ __device__ __forceinline__ HumanRegs load_human(const DevState &s, const LaneMap
 // (the profile of the first fused kernel showed 73 % of the service wave's cycles in s_waitcnt).
 #define EBC_MAXT 4  // observation rows per lane that are preloaded (R <= 4 N); more fall back to late loads
 struct CommitPre {
-  double px0, py0, vx0, vy0;  // reset() scene of this human (auto-reset)
-  double r0[9];               // reset() robot (leader lanes)
+  int cursor;  // pool slot this env restarts from (auto-reset)
   double sx[EBC_MAXT], sy[EBC_MAXT], sr[EBC_MAXT];  // static rows this lane will emit
+  // the restart scene (second-stage loads behind `cursor`; issued at the start of the kernel so
+  // that they are back long before the restore, and pinned with everything else)
+  double px, py, vx, vy, gx, gy, rad, vpref, spx, spy, srad, robot[9];
+  int type, n_humans, n_static;
 };
 
 __device__ __forceinline__ CommitPre preload_commit(const DevState &s, const StepIO &io, const LaneMap &m) {
   CommitPre c;
-  c.px0 = c.py0 = c.vx0 = c.vy0 = 0;
-  if (io.auto_reset && m.env_ok) {
-    c.px0 = s.px0[m.k];
-    c.py0 = s.py0[m.k];
-    c.vx0 = s.vx0[m.k];
-    c.vy0 = s.vy0[m.k];
-  }
-#pragma unroll
-  for (int q = 0; q < 9; ++q) c.r0[q] = (io.auto_reset && m.leader) ? s.robot0[m.ee * 9 + q] : 0.0;
 #pragma unroll
   for (int t = 0; t < EBC_MAXT; ++t) {
     const int r = m.i + t * s.N;
@@ -281,18 +293,53 @@ __device__ __forceinline__ CommitPre preload_commit(const DevState &s, const Ste
     c.sy[t] = st ? s.spy[q] : 0.0;
     c.sr[t] = st ? s.sradius[q] : 0.0;
   }
+  c.cursor = 0;
+  c.px = c.py = c.vx = c.vy = c.gx = c.gy = c.rad = c.vpref = c.spx = c.spy = c.srad = 0;
+  c.type = c.n_humans = c.n_static = 0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) c.robot[q] = 0;
+  if (io.auto_reset && m.env_ok) {
+    const ScenePool &P = s.pool;
+    c.cursor = P.cursor[m.ee];
+    const size_t src = (size_t)c.cursor * s.N + m.i;
+    c.n_humans = P.n_humans[c.cursor];
+    c.px = P.px[src]; c.py = P.py[src]; c.vx = P.vx[src]; c.vy = P.vy[src];
+    c.gx = P.gx[src]; c.gy = P.gy[src]; c.rad = P.radius[src]; c.vpref = P.v_pref[src];
+    c.type = P.type[src];
+    if (s.S) {
+      c.n_static = P.n_static[c.cursor];
+      if (m.i < s.S) {  // static rows: lane i carries row i (rows past N - 1 are copied late)
+        const size_t q = (size_t)c.cursor * s.S + m.i;
+        c.spx = P.spx[q]; c.spy = P.spy[q]; c.srad = P.sradius[q];
+      }
+    }
+    if (m.leader) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) c.robot[q] = P.robot[(size_t)c.cursor * 9 + q];
+    }
+  }
   return c;
 }
 
 __device__ __forceinline__ void pin_loads(HumanRegs &h, CommitPre &c, double (&rb)[9], double &gtime) {
   pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.gx); pin(h.gy); pin(h.rad); pin(h.vpref);
   pin(h.arrival); pin(h.type);
-  pin(c.px0); pin(c.py0); pin(c.vx0); pin(c.vy0);
+  pin(c.cursor);
 #pragma unroll
-  for (int q = 0; q < 9; ++q) { pin(c.r0[q]); pin(rb[q]); }
+  for (int q = 0; q < 9; ++q) pin(rb[q]);
 #pragma unroll
   for (int t = 0; t < EBC_MAXT; ++t) { pin(c.sx[t]); pin(c.sy[t]); pin(c.sr[t]); }
   pin(gtime);
+}
+
+// The restart scene is loaded behind `cursor` (one more memory round trip than the state).  It is
+// pinned later than the rest: just before service_commit's first store, after the arithmetic of
+// the commit, so the extra round trip overlaps that arithmetic instead of heading the chain.
+__device__ __forceinline__ void pin_pool(CommitPre &c) {
+  pin(c.px); pin(c.py); pin(c.vx); pin(c.vy); pin(c.gx); pin(c.gy); pin(c.rad); pin(c.vpref);
+  pin(c.spx); pin(c.spy); pin(c.srad); pin(c.type); pin(c.n_humans); pin(c.n_static);
+#pragma unroll
+  for (int q = 0; q < 9; ++q) pin(c.robot[q]);
 }
 
 // Where service_commit stores, as VGPR addresses fixed at the start of the kernel.
@@ -325,6 +372,8 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
   __shared__ double sh_ract[EBC_WAVE][2];
   __shared__ uint8_t sh_type[EBC_WAVE];
   const double dt = p.time_step;
+  int grid_slot = (m.leader && s.pool.grid) ? s.grid_scene[m.ee] : 0;
+  pin(grid_slot);
   if (m.leader) {
     double a0, a1;
     if (io.robot_policy == EBC_ROBOT_LINEAR) {
@@ -365,7 +414,7 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
   double nx, ny;
   robot_next_position(rb, p.robot_kinematics, a0, a1, dt, nx, ny);
   int coll[4] = {c0, c1, c2, 0};
-  coll[3] = grid_collision(s.grid ? s.grid + m.ee * s.G * 2 : nullptr, s.G, p.map_size_m,
+  coll[3] = grid_collision(s.pool.grid ? s.pool.grid + (size_t)grid_slot * s.G * 2 : nullptr, s.G, p.map_size_m,
                            p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
   const RewardOut ro = reward_compute(p, nx, ny, rb[5], rb[6], rb[4], a1, gtime, dmin, coll);
   // Agent.step for the robot (agent.py:202-228)
@@ -399,17 +448,11 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
 // rbn: the robot's next state (in registers); (ax, ay): this human's velocity.
 template <int T>
 __device__ __forceinline__ void service_commit(const EbcParams &p, const DevState &s, const StepIO &io,
-                                               const LaneMap &m, HumanRegs h, const CommitPre &pre,
+                                               const LaneMap &m, HumanRegs h, CommitPre pre,
                                                const CommitAddr &A, const double (&rbn)[9],
                                                bool restore, double tnew, double ax, double ay) {
   const int N = s.N, S = s.S, R = N + S;
   const double dt = p.time_step;
-  if (m.leader) {
-    // the robot: the moved state, or the reset() scene after a terminal step
-#pragma unroll
-    for (int c = 0; c < 9; ++c) A.robot[c] = restore ? pre.r0[c] : rbn[c];
-    *A.time = restore ? 0.0 : tnew;
-  }
   if (m.active) {  // Agent.step (agent.py:202-211), first arrival (env.py:365-378)
     h.px = h.px + ax * dt;
     h.py = h.py + ay * dt;
@@ -420,13 +463,19 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
     ax = 0;
     ay = 0;
   }
+  const RotFrame f = rot_frame(rbn, p.rotate_unicycle);
+  pin_pool(pre);  // first store of the commit below
+  if (m.leader && !restore) {  // the robot: the moved state (the restart scene: restore path)
+#pragma unroll
+    for (int c = 0; c < 9; ++c) A.robot[c] = rbn[c];
+    *A.time = tnew;
+  }
   if (A.human_action) {
     A.human_action[0] = ax;
     A.human_action[1] = ay;
   }
   // returned observation: humans then static rows, raw and in the robot frame
   if (io.ob || io.obs_rotated) {
-    const RotFrame f = rot_frame(rbn, p.rotate_unicycle);
     int t = 0;
     for (int r = m.i; r < R; r += N, ++t) {
       double opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
@@ -465,15 +514,8 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
       }
     }
   }
-  // the humans: the moved state, or the reset() scene after a terminal step
-  if (m.active) {
-    if (restore) {
-      h.px = pre.px0;
-      h.py = pre.py0;
-      h.vx = pre.vx0;
-      h.vy = pre.vy0;
-      h.arrival = 0;
-    }
+  // the humans: the moved state ...
+  if (m.active && !restore) {
     *A.px = h.px;
     *A.py = h.py;
     *A.vx = h.vx;
@@ -489,6 +531,49 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
     *A.fmax = (float)h.vpref;
     *A.fprefx = prefx;
     *A.fprefy = prefy;
+  }
+  // ... or, after a terminal step under auto-reset, the env's next scene from the pool: every
+  // per-scene field (ragged human count, goals, radii, static rows, map), time 0.  Rare path: its
+  // loads sit behind the step's stores on purpose.
+  if (restore) {
+    const ScenePool &P = s.pool;
+    const int n_new = pre.n_humans;
+    const bool live = m.i < n_new;
+    const double npx = live ? pre.px : 0.0, npy = live ? pre.py : 0.0;
+    const double nvx = live ? pre.vx : 0.0, nvy = live ? pre.vy : 0.0;
+    const double ngx = live ? pre.gx : 0.0, ngy = live ? pre.gy : 0.0;
+    const double nrad = live ? pre.rad : 0.0, nvp = live ? pre.vpref : 0.0;
+    *A.px = npx; *A.py = npy; *A.vx = nvx; *A.vy = nvy; *A.arrival = 0.0;
+    s.gx[m.k] = ngx; s.gy[m.k] = ngy; s.radius[m.k] = nrad; s.v_pref[m.k] = nvp;
+    s.type[m.k] = live ? (uint8_t)pre.type : (uint8_t)0;
+    if (live) {
+      store_tile(p, s, m.k, npx, npy, nvx, nvy, ngx, ngy, nrad, nvp);
+    } else {
+      *A.fpx = 0; *A.fpy = 0; *A.fvx = 0; *A.fvy = 0; *A.frad = 0; *A.fmax = 0; *A.fprefx = 0; *A.fprefy = 0;
+    }
+    if (m.i < S) {
+      s.spx[m.ee * S + m.i] = pre.spx;
+      s.spy[m.ee * S + m.i] = pre.spy;
+      s.sradius[m.ee * S + m.i] = pre.srad;
+    }
+    for (int q = m.i + N; q < S; q += N) {  // more static rows than humans: late loads (rare)
+      const size_t c = (size_t)pre.cursor * S + q;
+      s.spx[m.ee * S + q] = P.spx[c];
+      s.spy[m.ee * S + q] = P.spy[c];
+      s.sradius[m.ee * S + q] = P.sradius[c];
+    }
+    if (m.leader) {
+      s.n_humans[m.ee] = n_new;
+      if (S) s.n_static[m.ee] = pre.n_static;
+      s.grid_scene[m.ee] = pre.cursor;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) A.robot[q] = pre.robot[q];
+      *A.time = 0.0;
+      if (P.P > 0) {  // walk the custom pool; without one the env keeps restarting from its own slot
+        int nxt = pre.cursor - s.E + P.stride;
+        P.cursor[m.ee] = s.E + (nxt >= P.P ? nxt % P.P : nxt);
+      }
+    }
   }
 }
 
@@ -765,6 +850,7 @@ __global__ __launch_bounds__(EBC_LA_THREADS) void lookahead_kernel(EbcParams p, 
 
   // phase B2
   const double gtime = s.time[e];
+  const int grid_slot = s.pool.grid ? s.grid_scene[e] : 0;
   for (int a = tid; a < A; a += EBC_LA_THREADS) {
     const double a0 = io.actions[2 * a], a1 = io.actions[2 * a + 1];
     double dm0 = INFINITY, dm1 = INFINITY, dm2 = INFINITY;
@@ -781,7 +867,7 @@ __global__ __launch_bounds__(EBC_LA_THREADS) void lookahead_kernel(EbcParams p, 
     double nx, ny;
     robot_next_position(rb, p.robot_kinematics, a0, a1, dt, nx, ny);
     int coll[4] = {c0, c1, c2, 0};
-    coll[3] = grid_collision(s.grid ? s.grid + (size_t)e * s.G * 2 : nullptr, s.G, p.map_size_m,
+    coll[3] = grid_collision(s.pool.grid ? s.pool.grid + (size_t)grid_slot * s.G * 2 : nullptr, s.G, p.map_size_m,
                              p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
     const RewardOut ro = reward_compute(p, nx, ny, rb[5], rb[6], rb[4], a1, gtime, dmin, coll);
     const size_t o = (size_t)e * A + a;

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -42,9 +43,9 @@ struct Handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   bool has_reset = false;
-  bool has_grid = false;
   int orca_gs = 16;  // lanes per human of the ORCA waves (8 / 16 / 32)
-  uint64_t *grid_alloc = nullptr;
+  std::vector<void *> pool_allocs;   // pool arrays (re-allocated by ebc_set_scene_pool)
+  uint64_t *pool_grid_alloc = nullptr;
   // staging for host-location calls
   void *stage = nullptr;
   size_t stage_bytes = 0;
@@ -186,6 +187,118 @@ int launch_lookahead(Handle *h, const LookIO &io) {
   return EBC_OK;
 }
 
+// Destination arrays of a scene upload: the live state or the scene pool.
+struct SceneDst {
+  int *n_humans;
+  double *px, *py, *vx, *vy, *gx, *gy, *radius, *v_pref;
+  uint8_t *type;
+  int *n_static;
+  double *spx, *spy, *sradius;
+  uint64_t *grid;  // destination rows, written when the scene has a grid (or zeroed when `zero_grid`)
+  double *robot;
+};
+
+// Pool arrays hold E reset slots + P custom scenes.  Re-allocation (ebc_set_scene_pool) keeps the
+// reset slots.
+int alloc_pool(Handle *h, int P) {
+  ebc::ScenePool old = h->s.pool;
+  std::vector<void *> old_allocs = h->pool_allocs;
+  uint64_t *old_grid = h->pool_grid_alloc;
+  h->pool_allocs.clear();
+  ebc::ScenePool &pl = h->s.pool;
+  const int E = h->s.E;
+  const size_t slots = (size_t)E + P;
+  const size_t PN = slots * h->s.N, PS = slots * (h->s.S ? h->s.S : 1);
+  const size_t EN = (size_t)E * h->s.N, ES = (size_t)E * (h->s.S ? h->s.S : 1);
+  const bool keep = !old_allocs.empty();
+  auto get = [&](auto **out, size_t count, const void *from, size_t keep_count) -> int {
+    void *ptr = nullptr;
+    const size_t bytes = count * sizeof(**out) + 16;
+    HIP_TRY(hipMalloc(&ptr, bytes));
+    HIP_TRY(hipMemset(ptr, 0, bytes));
+    if (keep && from) HIP_TRY(hipMemcpy(ptr, from, keep_count * sizeof(**out), hipMemcpyDeviceToDevice));
+    h->pool_allocs.push_back(ptr);
+    *out = reinterpret_cast<std::remove_reference_t<decltype(*out)>>(ptr);
+    return EBC_OK;
+  };
+  int rc = EBC_OK;
+#define G_(f, c, k) if (rc == EBC_OK) rc = get(&pl.f, (c), old.f, (k))
+  G_(n_humans, slots, E); G_(px, PN, EN); G_(py, PN, EN); G_(vx, PN, EN); G_(vy, PN, EN); G_(gx, PN, EN);
+  G_(gy, PN, EN); G_(radius, PN, EN); G_(v_pref, PN, EN); G_(type, PN, EN); G_(n_static, slots, E);
+  G_(spx, PS, ES); G_(spy, PS, ES); G_(sradius, PS, ES); G_(robot, slots * 9, (size_t)E * 9);
+#undef G_
+  if (rc == EBC_OK) rc = get(&h->pool_grid_alloc, slots * h->s.G * 2, old_grid, (size_t)E * h->s.G * 2);
+  pl.grid = (keep && old.grid) ? h->pool_grid_alloc : nullptr;
+  pl.P = P;
+  pl.stride = 0;
+  pl.cursor = old.cursor;
+  for (void *ptr : old_allocs) (void)hipFree(ptr);
+  return rc;
+}
+
+// Copy rows of `sc` to rows `ids` (or 0..n-1) of `d`.
+int upload_scene(Handle *h, const EbcScene *sc, const int32_t *ids, const SceneDst &d, bool with_grid) {
+  const int n = sc->n, N = h->s.N, S = h->s.S, G = h->s.G;
+  bool contiguous = true;
+  if (ids)
+    for (int r = 0; r < n; ++r)
+      if (ids[r] != ids[0] + r) contiguous = false;
+  auto up = [&](void *dst_base, const void *src, size_t row_bytes) -> int {
+    if (!src) return EBC_OK;
+    if (contiguous) {
+      const int e0 = ids ? ids[0] : 0;
+      HIP_TRY(hipMemcpy((char *)dst_base + (size_t)e0 * row_bytes, src, (size_t)n * row_bytes, hipMemcpyHostToDevice));
+    } else {
+      for (int r = 0; r < n; ++r)
+        HIP_TRY(hipMemcpy((char *)dst_base + (size_t)ids[r] * row_bytes, (const char *)src + (size_t)r * row_bytes,
+                          row_bytes, hipMemcpyHostToDevice));
+    }
+    return EBC_OK;
+  };
+  int rc;
+  const size_t rowN = (size_t)N * sizeof(double);
+#define UP_(dst, src, bytes) if ((rc = up((void *)(dst), (const void *)(src), (bytes))) != EBC_OK) return rc
+  UP_(d.n_humans, sc->n_humans, sizeof(int));
+  UP_(d.px, sc->px, rowN); UP_(d.py, sc->py, rowN); UP_(d.vx, sc->vx, rowN); UP_(d.vy, sc->vy, rowN);
+  UP_(d.gx, sc->gx, rowN); UP_(d.gy, sc->gy, rowN); UP_(d.radius, sc->radius, rowN);
+  UP_(d.v_pref, sc->v_pref, rowN); UP_(d.type, sc->type, (size_t)N);
+  UP_(d.robot, sc->robot, 9 * sizeof(double));
+  if (S > 0) {
+    UP_(d.n_static, sc->n_static, sizeof(int));
+    UP_(d.spx, sc->spx, (size_t)S * sizeof(double)); UP_(d.spy, sc->spy, (size_t)S * sizeof(double));
+    UP_(d.sradius, sc->sradius, (size_t)S * sizeof(double));
+  }
+  const size_t grow = (size_t)G * 2 * sizeof(uint64_t);
+  if (sc->grid) {
+    UP_(d.grid, sc->grid, grow);
+  } else if (with_grid) {  // these rows get a free map
+    std::vector<uint64_t> zeros((size_t)n * G * 2, 0);
+    UP_(d.grid, zeros.data(), grow);
+  }
+#undef UP_
+  return EBC_OK;
+}
+
+int validate_scene(const Handle *h, const EbcScene *sc, const int32_t *ids, int id_limit) {
+  const int N = h->s.N, S = h->s.S;
+  if (!sc || sc->struct_size != sizeof(EbcScene)) return fail(EBC_ERR_INVALID, "EbcScene.struct_size");
+  if (sc->n <= 0) return fail(EBC_ERR_INVALID, "scene.n");
+  if (!sc->n_humans || !sc->px || !sc->py || !sc->vx || !sc->vy || !sc->gx || !sc->gy || !sc->radius ||
+      !sc->v_pref || !sc->type || !sc->robot)
+    return fail(EBC_ERR_INVALID, "scene array missing");
+  if (S > 0 && (!sc->n_static || !sc->spx || !sc->spy || !sc->sradius))
+    return fail(EBC_ERR_INVALID, "static rows missing");
+  for (int r = 0; r < sc->n; ++r) {  // what the kernels assume, checked on the host
+    const int e = ids ? ids[r] : r;
+    if (e < 0 || e >= id_limit) return fail(EBC_ERR_INVALID, "env id out of range");
+    if (sc->n_humans[r] < 0 || sc->n_humans[r] > N) return fail(EBC_ERR_INVALID, "n_humans > max_humans");
+    if (S > 0 && (sc->n_static[r] < 0 || sc->n_static[r] > S)) return fail(EBC_ERR_INVALID, "n_static > max_static");
+    for (int i = 0; i < sc->n_humans[r]; ++i)
+      if (sc->type[(size_t)r * N + i] > EBC_CHILD) return fail(EBC_ERR_INVALID, "human type must be 0..2");
+  }
+  return EBC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -258,16 +371,16 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   A_(radius, EN); A_(v_pref, EN); A_(type, EN); A_(n_static, n_envs); A_(spx, ES); A_(spy, ES);
   A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN); A_(fpx, EN); A_(fpy, EN); A_(fvx, EN); A_(fvy, EN); A_(frad, EN);
   A_(fmax, EN); A_(fprefx, EN); A_(fprefy, EN);
-  A_(done, n_envs); A_(hact, EN * 2); A_(px0, EN); A_(py0, EN); A_(vx0, EN); A_(vy0, EN);
-  A_(robot0, (size_t)n_envs * 9);
+  A_(done, n_envs); A_(hact, EN * 2);
 #undef A_
-  if (rc == EBC_OK) rc = dev_alloc(h, &h->grid_alloc, (size_t)n_envs * G * 2);
+  if (rc == EBC_OK) rc = dev_alloc(h, &s.pool.cursor, n_envs);
+  if (rc == EBC_OK) rc = dev_alloc(h, &s.grid_scene, n_envs);
+  if (rc == EBC_OK) rc = alloc_pool(h, 0);
   if (rc != EBC_OK) {
     for (void *ptr : h->allocs) (void)hipFree(ptr);
     delete h;
     return rc;
   }
-  s.grid = nullptr;
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
     for (void *ptr : h->allocs) (void)hipFree(ptr);
     delete h;
@@ -289,6 +402,7 @@ int ebc_destroy(void *handle) {
   if (rc) return rc;
   (void)hipStreamSynchronize(h->stream);
   for (void *ptr : h->allocs) (void)hipFree(ptr);
+  for (void *ptr : h->pool_allocs) (void)hipFree(ptr);
   if (h->stage) (void)hipFree(h->stage);
   for (hipEvent_t ev : h->ev) (void)hipEventDestroy(ev);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -325,84 +439,79 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *sc) {
   Handle *h;
   int rc = check_handle(handle, &h);
   if (rc) return rc;
-  if (!sc || sc->struct_size != sizeof(EbcScene)) return fail(EBC_ERR_INVALID, "EbcScene.struct_size");
   DevState &s = h->s;
-  const int n = sc->n, N = s.N, S = s.S, G = s.G;
-  if (n <= 0 || n > s.E) return fail(EBC_ERR_INVALID, "scene.n out of range");
-  if (!sc->n_humans || !sc->px || !sc->py || !sc->vx || !sc->vy || !sc->gx || !sc->gy ||
-      !sc->radius || !sc->v_pref || !sc->type || !sc->robot)
-    return fail(EBC_ERR_INVALID, "scene array missing");
-  if (S > 0 && (!sc->n_static || !sc->spx || !sc->spy || !sc->sradius))
-    return fail(EBC_ERR_INVALID, "static rows missing");
-  // validate on the host what the kernels assume
-  for (int r = 0; r < n; ++r) {
-    const int e = env_ids ? env_ids[r] : r;
-    if (e < 0 || e >= s.E) return fail(EBC_ERR_INVALID, "env id out of range");
-    if (sc->n_humans[r] < 0 || sc->n_humans[r] > N) return fail(EBC_ERR_INVALID, "n_humans > max_humans");
-    if (S > 0 && (sc->n_static[r] < 0 || sc->n_static[r] > S))
-      return fail(EBC_ERR_INVALID, "n_static > max_static");
-    for (int i = 0; i < sc->n_humans[r]; ++i)
-      if (sc->type[(size_t)r * N + i] > EBC_CHILD) return fail(EBC_ERR_INVALID, "human type must be 0..2");
-  }
+  if ((rc = validate_scene(h, sc, env_ids, s.E)) != EBC_OK) return rc;
+  const int n = sc->n, N = s.N;
+  if (n > s.E) return fail(EBC_ERR_INVALID, "scene.n out of range");
   HIP_TRY(hipStreamSynchronize(h->stream));
-  const bool contiguous = [&] {
-    if (!env_ids) return true;
-    for (int r = 0; r < n; ++r)
-      if (env_ids[r] != env_ids[0] + r) return false;
-    return true;
-  }();
-  auto up = [&](void *dst_base, const void *src, size_t row_bytes) -> int {
-    if (!src) return EBC_OK;
-    if (contiguous) {
-      const int e0 = env_ids ? env_ids[0] : 0;
-      HIP_TRY(hipMemcpy((char *)dst_base + (size_t)e0 * row_bytes, src, (size_t)n * row_bytes,
-                        hipMemcpyHostToDevice));
-    } else {
-      for (int r = 0; r < n; ++r)
-        HIP_TRY(hipMemcpy((char *)dst_base + (size_t)env_ids[r] * row_bytes,
-                          (const char *)src + (size_t)r * row_bytes, row_bytes, hipMemcpyHostToDevice));
-    }
-    return EBC_OK;
-  };
+  ebc::ScenePool &pl = s.pool;
+  if (sc->grid) pl.grid = h->pool_grid_alloc;
+  // the live state ...
+  const SceneDst live = {s.n_humans, s.px, s.py, s.vx, s.vy, s.gx, s.gy, s.radius, s.v_pref, s.type,
+                         s.n_static, s.spx, s.spy, s.sradius, nullptr, s.robot};
+  EbcScene no_grid = *sc;
+  no_grid.grid = nullptr;
+  if ((rc = upload_scene(h, &no_grid, env_ids, live, false)) != EBC_OK) return rc;
+  // ... and reset slot e of the pool (auto-reset source, and the home of env e's occupancy grid)
+  const SceneDst slot = {pl.n_humans, pl.px, pl.py, pl.vx, pl.vy, pl.gx, pl.gy, pl.radius, pl.v_pref,
+                         pl.type, pl.n_static, pl.spx, pl.spy, pl.sradius, h->pool_grid_alloc, pl.robot};
+  if ((rc = upload_scene(h, sc, env_ids, slot, pl.grid != nullptr)) != EBC_OK) return rc;
+  // per-env scalars: global_time = 0, arrival = 0, done = 0 (env.py:149-151); grid and restart slot
+  bool contiguous = true;
+  for (int r = 0; r < n && env_ids; ++r)
+    if (env_ids[r] != env_ids[0] + r) contiguous = false;
+  std::vector<int> ids(n);
+  for (int r = 0; r < n; ++r) ids[r] = env_ids ? env_ids[r] : r;
   const size_t rowN = (size_t)N * sizeof(double);
-#define UP_(dst, src, bytes) if ((rc = up((void *)(dst), (const void *)(src), (bytes))) != EBC_OK) return rc
-  UP_(s.n_humans, sc->n_humans, sizeof(int));
-  UP_(s.px, sc->px, rowN); UP_(s.py, sc->py, rowN); UP_(s.vx, sc->vx, rowN); UP_(s.vy, sc->vy, rowN);
-  UP_(s.gx, sc->gx, rowN); UP_(s.gy, sc->gy, rowN); UP_(s.radius, sc->radius, rowN);
-  UP_(s.v_pref, sc->v_pref, rowN); UP_(s.type, sc->type, (size_t)N);
-  UP_(s.px0, sc->px, rowN); UP_(s.py0, sc->py, rowN); UP_(s.vx0, sc->vx, rowN); UP_(s.vy0, sc->vy, rowN);
-  UP_(s.robot, sc->robot, 9 * sizeof(double)); UP_(s.robot0, sc->robot, 9 * sizeof(double));
-  if (S > 0) {
-    UP_(s.n_static, sc->n_static, sizeof(int));
-    UP_(s.spx, sc->spx, (size_t)S * sizeof(double)); UP_(s.spy, sc->spy, (size_t)S * sizeof(double));
-    UP_(s.sradius, sc->sradius, (size_t)S * sizeof(double));
+  if (contiguous) {
+    const int e0 = ids[0];
+    HIP_TRY(hipMemset(s.time + e0, 0, (size_t)n * sizeof(double)));
+    HIP_TRY(hipMemset(s.arrival + (size_t)e0 * N, 0, (size_t)n * rowN));
+    HIP_TRY(hipMemset(s.done + e0, 0, (size_t)n));
+    HIP_TRY(hipMemcpy(s.grid_scene + e0, ids.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    if (pl.P == 0) HIP_TRY(hipMemcpy(pl.cursor + e0, ids.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  } else {
+    for (int r = 0; r < n; ++r) {
+      const int e = ids[r];
+      HIP_TRY(hipMemset(s.time + e, 0, sizeof(double)));
+      HIP_TRY(hipMemset(s.arrival + (size_t)e * N, 0, rowN));
+      HIP_TRY(hipMemset(s.done + e, 0, 1));
+      HIP_TRY(hipMemcpy(s.grid_scene + e, &e, sizeof(int), hipMemcpyHostToDevice));
+      if (pl.P == 0) HIP_TRY(hipMemcpy(pl.cursor + e, &e, sizeof(int), hipMemcpyHostToDevice));
+    }
   }
-  const size_t grow = (size_t)G * 2 * sizeof(uint64_t);
-  if (sc->grid) {
-    UP_(h->grid_alloc, sc->grid, grow);
-    h->has_grid = true;
-    s.grid = h->grid_alloc;
-  } else if (h->has_grid) {  // these envs get a free map
-    std::vector<uint64_t> zeros((size_t)n * G * 2, 0);
-    UP_(h->grid_alloc, zeros.data(), grow);
-  }
-#undef UP_
-  // global_time = 0, arrival times = 0, done = 0 (env.py:149-151)
-  for (int r = 0; r < n; ++r) {
-    const int e = env_ids ? env_ids[r] : r;
-    const int cnt = contiguous ? n : 1;
-    HIP_TRY(hipMemset(s.time + e, 0, (size_t)cnt * sizeof(double)));
-    HIP_TRY(hipMemset(s.arrival + (size_t)e * N, 0, (size_t)cnt * rowN));
-    HIP_TRY(hipMemset(s.done + e, 0, (size_t)cnt));
-    if (contiguous) break;
-  }
-  {  // the float tile the ORCA role reads (orca.py:110-140), for the whole batch
+  {  // the float tile the ORCA waves read (orca.py:110-140), for the whole batch
     const size_t EN = (size_t)s.E * N;
     hipLaunchKernelGGL(ebc::tile_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0, h->stream, h->p, h->s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
   h->has_reset = true;
+  return EBC_OK;
+}
+
+int ebc_set_scene_pool(void *handle, const EbcScene *sc, int stride) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  DevState &s = h->s;
+  if ((rc = validate_scene(h, sc, nullptr, sc ? sc->n : 0)) != EBC_OK) return rc;
+  if (stride < 0) return fail(EBC_ERR_INVALID, "stride");
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int P = sc->n, E = s.E;
+  if ((rc = alloc_pool(h, P)) != EBC_OK) return rc;  // keeps the E reset slots
+  ebc::ScenePool &pl = s.pool;
+  if (sc->grid) pl.grid = h->pool_grid_alloc;
+  const size_t N = s.N, S = s.S ? s.S : 1;
+  const SceneDst slot = {pl.n_humans + E, pl.px + E * N, pl.py + E * N, pl.vx + E * N, pl.vy + E * N,
+                         pl.gx + E * N, pl.gy + E * N, pl.radius + E * N, pl.v_pref + E * N, pl.type + E * N,
+                         pl.n_static + E, pl.spx + E * S, pl.spy + E * S, pl.sradius + E * S,
+                         h->pool_grid_alloc + (size_t)E * s.G * 2, pl.robot + (size_t)E * 9};
+  if ((rc = upload_scene(h, sc, nullptr, slot, false)) != EBC_OK) return rc;
+  pl.stride = stride % P;
+  std::vector<int> cur(E);
+  for (int e = 0; e < E; ++e) cur[e] = E + e % P;
+  HIP_TRY(hipMemcpy(pl.cursor, cur.data(), (size_t)E * sizeof(int), hipMemcpyHostToDevice));
   return EBC_OK;
 }
 

@@ -20,6 +20,7 @@ SYMBOLS = {
     "ebc_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_synchronize": (C.c_int, [C.c_void_p]),
     "ebc_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ebc_set_scene_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ebc_set_human_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ebc_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ebc_step": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -42,18 +42,15 @@ class BatchedEnv:
             pass
 
     # ------------------------------------------------------------------ reset
-    def reset(self, scene, env_ids=None):
-        """scene: ebcsim.scene.SceneBatch padded to (max_humans, max_static)."""
-        if scene.N != self.N or scene.S != self.S:
-            raise ValueError("scene batch padded to (%d, %d), env expects (%d, %d)"
-                             % (scene.N, scene.S, self.N, self.S))
-        keep = []
-
+    def _scene_struct(self, scene, keep):
         def arr(a, dtype):
             a = np.ascontiguousarray(a, dtype=dtype)
             keep.append(a)
             return a.ctypes.data
 
+        if scene.N != self.N or scene.S != self.S:
+            raise ValueError("scene batch padded to (%d, %d), env expects (%d, %d)"
+                             % (scene.N, scene.S, self.N, self.S))
         sc = _abi.EbcScene()
         sc.struct_size = C.sizeof(sc)
         sc.n = scene.n
@@ -70,6 +67,12 @@ class BatchedEnv:
                 raise ValueError("grid must be [n][%d][2] uint64" % self.G)
             sc.grid = arr(scene.grid, np.uint64)
         sc.robot = arr(scene.robot, np.float64)
+        return sc
+
+    def reset(self, scene, env_ids=None):
+        """scene: ebcsim.scene.SceneBatch padded to (max_humans, max_static)."""
+        keep = []
+        sc = self._scene_struct(scene, keep)
         ids = None
         if env_ids is not None:
             ids = np.ascontiguousarray(env_ids, dtype=np.int32)
@@ -80,6 +83,13 @@ class BatchedEnv:
             self.n_static_host = np.zeros(self.E, dtype=np.int64)
         if self.S:
             self.n_static_host[np.arange(scene.n) if ids is None else ids] = scene.n_static
+
+    def set_scene_pool(self, scene, stride=None):
+        """Install P = scene.n host-generated scenes as the auto-reset pool; env e walks scenes
+        e mod P, + stride, ... (default stride = E: disjoint walks when P is a multiple of E)."""
+        keep = []
+        sc = self._scene_struct(scene, keep)
+        _capi.check(self._L.ebc_set_scene_pool(self._h, C.addressof(sc), int(self.E if stride is None else stride)))
 
     # ------------------------------------------------------------------ host calls
     def set_human_actions(self, act):

@@ -218,6 +218,14 @@ int ebc_synchronize(void *handle);
  * for EBC_FLAG_AUTO_RESET.  env_ids NULL = envs 0..n-1. */
 int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *scene);
 
+/* Device-resident scene pool for EBC_FLAG_AUTO_RESET (the reference generates a fresh scene at
+ * every env.reset on the host, simulator/scene/scene_generator.py:330-378; with thousands of envs
+ * resets would dominate).  `pool` holds P host-generated scenes (same layout as for ebc_reset,
+ * scene.n = P).  Env e restarts from scene cursor[e] = e mod P, and the cursor then advances by
+ * `stride` (mod P), entirely on the device.  Without this call the pool is the envs' own
+ * ebc_reset scenes (P = E, stride 0).  Does not touch the running episodes. */
+int ebc_set_scene_pool(void *handle, const EbcScene *pool, int stride);
+
 /* Humans moved by the host (BASELINE config 2): act[E][N][2]. */
 int ebc_set_human_actions(void *handle, int location, const double *act);
 

@@ -30,15 +30,24 @@ typedef struct OrcState {
   uint8_t *type;                                           /* [E][N] */
   int32_t *n_static;                                       /* [E] */
   double *spx, *spy, *sradius;                             /* [E][S] */
-  uint64_t *grid;                                          /* [E][G][2] or NULL */
+  int32_t *grid_scene;                                     /* [E] pool slot whose grid env e uses */
   double *robot;                                           /* [E][9] */
   double *global_time;                                     /* [E] */
   double *arrival_time;                                    /* [E][N] */
   uint8_t *done;                                           /* [E] */
   double *human_action;                                    /* [E][N][2] external / cached */
-  /* reset() copies for EBC_FLAG_AUTO_RESET */
-  double *px0, *py0, *vx0, *vy0;                           /* [E][N] */
-  double *robot0;                                          /* [E][9] */
+  /* scene pool for EBC_FLAG_AUTO_RESET, same layout: slots [0, E) = the envs' reset() scenes,
+   * slots [E, E + P) = the pool of ebc_set_scene_pool.  Env e restarts from slot cursor[e]: itself
+   * when P == 0, else it walks E + (e mod P), + stride, ... (mod P) */
+  int32_t P, stride;
+  int32_t *cursor;                                         /* [E] */
+  int32_t *p_n_humans;                                     /* [E + P] */
+  double *p_px, *p_py, *p_vx, *p_vy, *p_gx, *p_gy, *p_radius, *p_v_pref; /* [P][N] */
+  uint8_t *p_type;                                         /* [P][N] */
+  int32_t *p_n_static;                                     /* [P] */
+  double *p_spx, *p_spy, *p_sradius;                       /* [P][S] */
+  uint64_t *p_grid;                                        /* [P][G][2] or NULL */
+  double *p_robot;                                         /* [P][9] */
 } OrcState;
 
 double orc_point_to_segment_dist(double x1, double y1, double x2, double y2, double x3, double y3);

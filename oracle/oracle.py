@@ -69,8 +69,12 @@ class OrcState(C.Structure):
     _fields_ = [("E", C.c_int32), ("N", C.c_int32), ("S", C.c_int32), ("G", C.c_int32)] + [
         (k, C.c_void_p) for k in (
             "n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
-            "n_static", "spx", "spy", "sradius", "grid", "robot", "global_time",
-            "arrival_time", "done", "human_action", "px0", "py0", "vx0", "vy0", "robot0")
+            "n_static", "spx", "spy", "sradius", "grid_scene", "robot", "global_time",
+            "arrival_time", "done", "human_action")
+    ] + [("P", C.c_int32), ("stride", C.c_int32)] + [
+        (k, C.c_void_p) for k in (
+            "cursor", "p_n_humans", "p_px", "p_py", "p_vx", "p_vy", "p_gx", "p_gy", "p_radius",
+            "p_v_pref", "p_type", "p_n_static", "p_spx", "p_spy", "p_sradius", "p_grid", "p_robot")
     ]
 
 
@@ -177,42 +181,80 @@ class OracleEnv:
             gx=f(E, N), gy=f(E, N), radius=f(E, N), v_pref=f(E, N),
             type=np.zeros((E, N), np.uint8), n_static=np.zeros(E, np.int32),
             spx=f(E, S), spy=f(E, S), sradius=f(E, S),
-            grid=np.zeros((E, self.G, 2), np.uint64), robot=f(E, 9), global_time=f(E),
-            arrival_time=f(E, N), done=np.zeros(E, np.uint8), human_action=f(E, N, 2),
-            px0=f(E, N), py0=f(E, N), vx0=f(E, N), vy0=f(E, N), robot0=f(E, 9))
-        self.has_grid = False
+            grid_scene=np.arange(E, dtype=np.int32), robot=f(E, 9), global_time=f(E),
+            arrival_time=f(E, N), done=np.zeros(E, np.uint8), human_action=f(E, N, 2))
         self._st = OrcState()
+        self._alloc_pool(0)
+
+    _POOL_KEYS = ("n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
+                  "n_static", "spx", "spy", "sradius", "grid", "robot")
+
+    def _alloc_pool(self, P):
+        """E reset slots + P custom scenes; the reset slots survive a re-allocation."""
+        E, N, S = self.E, self.N, max(self.S, 1)
+        f = lambda *s: np.zeros(s, dtype=np.float64)  # noqa: E731
+        n = E + P
+        new = dict(
+            n_humans=np.zeros(n, np.int32), px=f(n, N), py=f(n, N), vx=f(n, N), vy=f(n, N),
+            gx=f(n, N), gy=f(n, N), radius=f(n, N), v_pref=f(n, N), type=np.zeros((n, N), np.uint8),
+            n_static=np.zeros(n, np.int32), spx=f(n, S), spy=f(n, S), sradius=f(n, S),
+            grid=np.zeros((n, self.G, 2), np.uint64), robot=f(n, 9))
+        if getattr(self, "pool", None) is not None:
+            for k in new:
+                new[k][:E] = self.pool[k][:E]
+        else:
+            self.pool_has_grid = False
+        self.pool = new
+        self.P, self.stride = P, 0
+        if P == 0:
+            self.cursor = np.arange(E, dtype=np.int32)
+
+    def _fill(self, dst, scene, ids, with_scene_rows=True):
+        for k in ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type"):
+            dst[k][ids] = getattr(scene, k)
+        dst["n_humans"][ids] = scene.n_humans
+        if self.S:
+            dst["n_static"][ids] = scene.n_static
+            dst["spx"][ids], dst["spy"][ids], dst["sradius"][ids] = scene.spx, scene.spy, scene.sradius
+        if "grid" in dst:
+            dst["grid"][ids] = scene.grid if scene.grid is not None else 0
+        dst["robot"][ids] = scene.robot
+
+    def set_scene_pool(self, scene, stride=None):
+        P, E = scene.n, self.E
+        self._alloc_pool(P)
+        self._fill(self.pool, scene, E + np.arange(P))
+        if scene.grid is not None:
+            self.pool_has_grid = True
+        self.stride = (E if stride is None else stride) % P
+        self.cursor = (E + np.arange(E) % P).astype(np.int32)
 
     def _state(self):
         st = self._st
         st.E, st.N, st.S, st.G = self.E, self.N, self.S, self.G
         for k, v in self.a.items():
             setattr(st, k, v.ctypes.data)
-        if not self.has_grid:
-            st.grid = None
+        st.P, st.stride = self.P, self.stride
+        st.cursor = self.cursor.ctypes.data
+        for k in self._POOL_KEYS:
+            setattr(st, "p_" + k, self.pool[k].ctypes.data)
+        if not self.pool_has_grid:
+            st.p_grid = None
         return st
 
     def reset(self, scene, env_ids=None):
         ids = np.arange(scene.n) if env_ids is None else np.asarray(env_ids)
         a = self.a
-        for k in ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type"):
-            a[k][ids] = getattr(scene, k)
-        a["n_humans"][ids] = scene.n_humans
-        if self.S:
-            a["n_static"][ids] = scene.n_static
-            a["spx"][ids], a["spy"][ids], a["sradius"][ids] = scene.spx, scene.spy, scene.sradius
-        if scene.grid is not None:
-            a["grid"][ids] = scene.grid
-            self.has_grid = True
-        else:
-            a["grid"][ids] = 0
-        a["robot"][ids] = scene.robot
+        self._fill(a, scene, ids)
         a["global_time"][ids] = 0
         a["arrival_time"][ids] = 0
         a["done"][ids] = 0
-        for k in ("px", "py", "vx", "vy"):
-            a[k + "0"][ids] = a[k][ids]
-        a["robot0"][ids] = a["robot"][ids]
+        a["grid_scene"][ids] = ids
+        self._fill(self.pool, scene, ids)  # reset slot e: restart source and home of env e's grid
+        if scene.grid is not None:
+            self.pool_has_grid = True
+        if self.P == 0:
+            self.cursor[ids] = ids
 
     def set_human_actions(self, act):
         self.a["human_action"][...] = np.asarray(act, dtype=np.float64).reshape(self.E, self.N, 2)

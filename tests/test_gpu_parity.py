@@ -391,3 +391,45 @@ def test_observe_is_the_returned_observation():
         np.testing.assert_array_equal(ob_g, out["ob"])
         np.testing.assert_array_equal(obs_g, out["obs_rotated"])
         np.testing.assert_allclose(obs_g, o.observe()[1], atol=1e-5, rtol=1e-5)
+
+
+def test_scene_pool_auto_reset():
+    """Device-resident scene pool: 3 E host-generated scenes with ragged human counts, different
+    goals / static rows / maps; every terminal env restarts from its next pool scene on the
+    device.  300 steps so that envs go through several episodes; every output every step against
+    the oracle, and the state after a restart equals the pool scene."""
+    from oracle import oracle
+    params = params_of(load("traj_n10_walls_t17_orcasub"))
+    params.time_limit = 6  # short episodes: many restarts
+    rs = np.random.RandomState(77)
+    E, N, S = 40, 8, 4
+    first = _synthetic_batch(rs, E, N, S, n_lo=2)
+    pool = _synthetic_batch(rs, 3 * E, N, S, n_lo=1)
+    g = _env(params, E, N, S)
+    o = oracle.OracleEnv(params, E, N, S)
+    for env in (g, o):
+        env.reset(first)
+        env.set_scene_pool(pool)
+    restarts = 0
+    seen_scene = np.zeros(E, int)
+    for t in range(300):
+        og = g.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=_abi.FLAG_AUTO_RESET)
+        oo = o.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=_abi.FLAG_AUTO_RESET)
+        _compare_step(og, oo, "pool step %d" % t)
+        if og["done"].any() and t % 7 == 0:
+            st = g.get_state()
+            for e in np.where(og["done"])[0]:
+                # after a restart the env holds a pool scene at time 0
+                assert st["global_time"][e] == 0
+                k = int(st["n_humans"][e])
+                cands = [c for c in range(e, 3 * E, E) if pool.n_humans[c] == k and
+                         np.array_equal(pool.px[c, :k], st["px"][e, :k])]
+                assert cands, (t, e)
+        restarts += int(og["done"].sum())
+    assert restarts > 3 * E
+    sg, so = g.get_state(), o.get_state()
+    for k in sg:
+        np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
+    ob_g, obs_g = g.observe()
+    ob_o, obs_o = o.observe()
+    np.testing.assert_array_equal(ob_g, ob_o)

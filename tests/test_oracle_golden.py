@@ -198,3 +198,37 @@ def test_angular_local_map():
                               m["dim"], m["angle_min"], m["angle_max"])
             np.testing.assert_array_equal(got, ref)
     assert (z["map_0"] < 1).any()
+
+
+def test_scene_pool_semantics_cpu():
+    """Auto-reset walks the pool: env e restarts from scenes e, e + E, e + 2E, ... (mod P)."""
+    z = load("traj_a5_linear_orcasub")
+    params = params_of(z)
+    params.time_limit = 1  # every env times out at step 5 (t = 1.0 >= 1)
+    b = batch_from_init(z, copies=2)
+    pool = batch_from_init(z, copies=6)
+    for c in range(6):
+        pool.px[c] += 0.001 * c  # make pool scenes distinguishable
+        pool.n_humans[c] = 5 - (c % 2)
+    env = oracle.OracleEnv(params, 2, b.N, b.S)
+    env.reset(b)
+    env.set_scene_pool(pool, stride=2)
+    visited = {0: [], 1: []}
+    for t in range(30):
+        out = env.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR,
+                       flags=_abi.FLAG_AUTO_RESET)
+        if out["done"].all():
+            st = env.get_state()
+            for e in (0, 1):
+                c = int(round((st["px"][e, 0] - z["init_px"][0]) / 0.001))
+                visited[e].append(c)
+                assert st["n_humans"][e] == pool.n_humans[c] and st["global_time"][e] == 0
+    assert visited[0][:4] == [0, 2, 4, 0] and visited[1][:4] == [1, 3, 5, 1]
+    # without a pool an env keeps restarting from its own reset() scene
+    env2 = oracle.OracleEnv(params, 2, b.N, b.S)
+    env2.reset(b)
+    for t in range(12):
+        out = env2.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR,
+                        flags=_abi.FLAG_AUTO_RESET)
+        if out["done"].all():
+            np.testing.assert_array_equal(env2.get_state()["px"], b.px)
