@@ -3,7 +3,7 @@
 // One env.step (simulator/env.py:388-466) = robot-side "service" work (lane per human: robot
 // action, collisions, reward, then human update + observation) plus the humans' ORCA velocities
 // (GS lanes per human, ebc_orca_group.h, over the float tile the previous step left in HBM).
-//   phase1_kernel<GS> + phase2_kernel<T>   ORCA humans, two launches: a heterogeneous grid of
+//   phase1_kernel<GS,K> + phase2_kernel<T>   ORCA humans, two launches: a heterogeneous grid of
 //                              one-wave workgroups (service_env waves at full lane use beside
 //                              ORCA waves; both read only pre-step state), then service_commit.
 //   step_kernel<POLICY,T>      humans on the linear policy or with supplied / cached velocities:
@@ -11,7 +11,7 @@
 // (A fused single-launch ORCA step -- service wave + ORCA waves per workgroup with an LDS
 // hand-off -- was built and measured: never faster than the split form on MI355X once the
 // service chain was cut down, and 1.6x slower at 4096 x 10; see DESIGN.md.)
-//   orca_kernel<GS>     ORCA alone -> hact (look-ahead prelude)
+//   orca_kernel<GS,K>   ORCA alone -> hact (look-ahead prelude)
 //   lookahead_kernel<T> the |A|-way onestep_lookahead sweep (multi_human_rl.py:38-61).
 //
 // HBM layout: struct-of-arrays [E][N] per human field (lane = e*N + i -> contiguous wave
@@ -56,9 +56,13 @@ struct DevState {
   uint8_t *done;  // terminal flag of the last step
   double *hact;   // [E][N][2] human velocities: ORCA role, ebc_set_human_actions, or look-ahead cache
   ScenePool pool;  // where auto-reset takes an env's next scene from
-  // what rvo2 would hold for the current state (float): position, velocity,
-  // radius + 0.01 + safety, maxSpeed, preferred velocity
-  float *fpx, *fpy, *fvx, *fvy, *frad, *fmax, *fprefx, *fprefy;
+  // what rvo2 would hold for the current state (float), one 32-byte record per human slot:
+  // tile[2k] = (position, velocity), tile[2k + 1] = (radius + 0.01 + safety, maxSpeed, preferred
+  // velocity).  An ORCA lane reads its human with two 16-byte loads and an "other" with 16 + 4.
+  float4 *tile;
+  // uniform ORCA constants (float, as rvo2 computes them) and the magic number of h / N
+  float inv_time_horizon, inv_time_step, range_sq;
+  unsigned n_magic, n_shift;
 };
 
 struct StepIO {
@@ -97,14 +101,9 @@ __device__ __forceinline__ void store_tile(const EbcParams &p, const DevState &s
                                            double rad, double vpref) {
   float prefx, prefy;
   orca_pref_velocity(px, py, gx, gy, prefx, prefy);
-  s.fpx[k] = (float)px;
-  s.fpy[k] = (float)py;
-  s.fvx[k] = (float)vx;
-  s.fvy[k] = (float)vy;
-  s.frad[k] = (float)(rad + 0.01 + p.orca_safety_space);  // orca.py:116, :122-126
-  s.fmax[k] = (float)vpref;                                // orca.py:117
-  s.fprefx[k] = prefx;
-  s.fprefy[k] = prefy;
+  s.tile[2 * k] = make_float4((float)px, (float)py, (float)vx, (float)vy);
+  // orca.py:116, :122-126 (radius), :117 (maxSpeed)
+  s.tile[2 * k + 1] = make_float4((float)(rad + 0.01 + p.orca_safety_space), (float)vpref, prefx, prefy);
 }
 
 __global__ __launch_bounds__(256) void tile_kernel(EbcParams p, DevState s) {
@@ -118,13 +117,24 @@ __global__ __launch_bounds__(256) void tile_kernel(EbcParams p, DevState s) {
 // (env.py:396-402): the humans before and after it, then the robot when it is visible.
 // `scratch` = this wave's private LDS (EBC_ORCA_LDS bytes).  Returns the group's velocity in
 // every lane of the group.
-#define EBC_ORCA_LDS (EBC_WAVE * 4 + 2 * EBC_WAVE * 16)
-template <int GS>
+// LDS of one ORCA wave: per group its distances and two line arrays.  64 / GS groups hold humans;
+// when GS does not divide 64 the left-over lanes form one more (idle) group with its own scratch.
+template <int GS, int K>
+struct OrcaLds {
+  using Sh = OrcaShape<GS, K>;
+  static constexpr int HPW = EBC_WAVE / GS;
+  static constexpr int GROUPS = (EBC_WAVE + GS - 1) / GS;
+  static constexpr int DIST = GROUPS * Sh::DIST * 4;
+  static constexpr int BYTES = DIST + 2 * GROUPS * Sh::LINES * 16;
+};
+
+template <int GS, int K>
 __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s, bool h_ok, int e, int i,
                                           unsigned char *scratch, float &ox, float &oy, bool &human_ok) {
+  using L = OrcaLds<GS, K>;
   float *dist_lds = reinterpret_cast<float *>(scratch);
-  float4 *lines_lds = reinterpret_cast<float4 *>(scratch + EBC_WAVE * 4);
-  float4 *proj_lds = lines_lds + EBC_WAVE;
+  float4 *lines_lds = reinterpret_cast<float4 *>(scratch + L::DIST);
+  float4 *proj_lds = lines_lds + L::GROUPS * L::Sh::LINES;
   const int N = s.N;
   const int lane = threadIdx.x & (EBC_WAVE - 1);
   const int group = lane / GS;
@@ -135,54 +145,77 @@ __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s,
   // tile loads do not wait for n_humans: indices are clamped into the env's row, validity is
   // decided afterwards (padded slots hold zeros)
   const size_t ks = base + i;
-  const int oj = j < i ? j : j + 1;
-  const size_t ko = base + (oj < N ? oj : N - 1);
   float posx = 0, posy = 0, velx = 0, vely = 0, radius = 0, maxSpeed = 0, prefx = 0, prefy = 0;
-  float opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
+  float opx[K], opy[K], ovx[K], ovy[K], orad[K];
   if (h_ok) {
-    posx = s.fpx[ks];
-    posy = s.fpy[ks];
-    velx = s.fvx[ks];
-    vely = s.fvy[ks];
-    radius = s.frad[ks];
-    maxSpeed = s.fmax[ks];
-    prefx = s.fprefx[ks];
-    prefy = s.fprefy[ks];
-    opx = s.fpx[ko];
-    opy = s.fpy[ko];
-    ovx = s.fvx[ko];
-    ovy = s.fvy[ko];
-    orad = s.frad[ko];
+    const float4 a = s.tile[2 * ks], b = s.tile[2 * ks + 1];
+    posx = a.x;
+    posy = a.y;
+    velx = a.z;
+    vely = a.w;
+    radius = b.x;
+    maxSpeed = b.y;
+    prefx = b.z;
+    prefy = b.w;
+  }
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const int item = q * GS + j;             // "other" index in ob order
+    const int oj = item < i ? item : item + 1;  // humans before / after this one
+    const size_t ko = base + (oj < N ? oj : N - 1);
+    opx[q] = opy[q] = ovx[q] = ovy[q] = orad[q] = 0.0f;
+    if (h_ok) {
+      const float4 a = s.tile[2 * ko];
+      opx[q] = a.x;
+      opy[q] = a.y;
+      ovx[q] = a.z;
+      ovy[q] = a.w;
+      orad[q] = s.tile[2 * ko + 1].x;
+    }
   }
   const int n_others = human_ok ? (n - 1 + (p.robot_visible ? 1 : 0)) : 0;
-  const bool valid = j < n_others;
-  if (p.robot_visible && valid && j == n - 1) {  // the robot, last in ob (env.py:401-402)
-    const double *rb = s.robot + (size_t)e * 9;
-    opx = (float)rb[0];
-    opy = (float)rb[1];
-    ovx = (float)rb[2];
-    ovy = (float)rb[3];
-    orad = (float)(rb[4] + 0.01 + p.orca_safety_space);
+  bool valid[K];
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    const int item = q * GS + j;
+    valid[q] = item < n_others;
+    if (p.robot_visible && valid[q] && item == n - 1) {  // the robot, last in ob (env.py:401-402)
+      const double *rb = s.robot + (size_t)e * 9;
+      opx[q] = (float)rb[0];
+      opy[q] = (float)rb[1];
+      ovx[q] = (float)rb[2];
+      ovy[q] = (float)rb[3];
+      orad[q] = (float)(rb[4] + 0.01 + p.orca_safety_space);
+    }
   }
-  orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy,
-                 ovx, ovy, orad, dist_lds + group * GS, lines_lds + group * GS, proj_lds + group * GS,
-                 N - 1 + (p.robot_visible ? 1 : 0), ox, oy);
+  orca_group<GS, K>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy,
+                    ovx, ovy, orad, dist_lds + group * L::Sh::DIST, lines_lds + group * L::Sh::LINES,
+                    proj_lds + group * L::Sh::LINES, N - 1 + (p.robot_visible ? 1 : 0), s.range_sq,
+                    s.inv_time_horizon, s.inv_time_step, ox, oy);
+}
+
+// (env, slot) of flat human index h < E * N without the ~20-instruction integer divide
+__device__ __forceinline__ void split_human(const DevState &s, unsigned h, bool h_ok, int &e, int &i) {
+  const unsigned N = (unsigned)s.N;
+  const unsigned q = N > 1 ? (__umulhi(h, s.n_magic) >> s.n_shift) : h;
+  e = h_ok ? (int)q : 0;
+  i = h_ok ? (int)(h - q * N) : 0;
 }
 
 // ORCA alone -> s.hact: the prelude of a look-ahead sweep (the following step re-uses it).
-template <int GS>
+template <int GS, int K>
 __global__ __launch_bounds__(EBC_WAVE) void orca_kernel(EbcParams p, DevState s) {
   constexpr int HPW = EBC_WAVE / GS;
-  __shared__ __align__(16) unsigned char scratch[EBC_ORCA_LDS];
+  __shared__ __align__(16) unsigned char scratch[OrcaLds<GS, K>::BYTES];
   const int group = threadIdx.x / GS, j = threadIdx.x - group * GS;
   const unsigned h = (unsigned)blockIdx.x * HPW + group;
   const unsigned N = (unsigned)s.N;
-  const bool h_ok = h < (unsigned)s.E * N;
-  const int e = h_ok ? (int)(h / N) : 0;
-  const int i = h_ok ? (int)(h - (unsigned)e * N) : 0;
+  const bool h_ok = group < HPW && h < (unsigned)s.E * N;  // lanes past HPW * GS idle
+  int e, i;
+  split_human(s, h, h_ok, e, i);
   float ox, oy;
   bool human_ok;
-  orca_wave<GS>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
+  orca_wave<GS, K>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
   if (h_ok && j == 0) {
     s.hact[(size_t)h * 2] = human_ok ? (double)ox : 0.0;  // getAgentVelocity -> Python float
     s.hact[(size_t)h * 2 + 1] = human_ok ? (double)oy : 0.0;
@@ -345,7 +378,8 @@ __device__ __forceinline__ void pin_pool(CommitPre &c) {
 // Where service_commit stores, as VGPR addresses fixed at the start of the kernel.
 struct CommitAddr {
   double *px, *py, *vx, *vy, *arrival, *robot, *time, *human_action, *ob;
-  float *fpx, *fpy, *fvx, *fvy, *frad, *fmax, *fprefx, *fprefy, *obs;
+  float4 *tile;
+  float *obs;
 };
 __device__ __forceinline__ CommitAddr commit_addr(const DevState &s, const StepIO &io, const LaneMap &m) {
   CommitAddr a;
@@ -356,11 +390,10 @@ __device__ __forceinline__ CommitAddr commit_addr(const DevState &s, const StepI
   a.human_action = io.human_action ? io.human_action + m.k * 2 : nullptr;
   a.ob = io.ob ? io.ob + m.ee * (size_t)(s.N + s.S) * 5 : nullptr;
   a.obs = io.obs_rotated;  // row offset depends on T: added by the caller
-  a.fpx = s.fpx + m.k; a.fpy = s.fpy + m.k; a.fvx = s.fvx + m.k; a.fvy = s.fvy + m.k;
-  a.frad = s.frad + m.k; a.fmax = s.fmax + m.k; a.fprefx = s.fprefx + m.k; a.fprefy = s.fprefy + m.k;
+  a.tile = s.tile + 2 * m.k;
   pin(a.px); pin(a.py); pin(a.vx); pin(a.vy); pin(a.arrival); pin(a.robot); pin(a.time);
   pin(a.human_action); pin(a.ob); pin(a.obs);
-  pin(a.fpx); pin(a.fpy); pin(a.fvx); pin(a.fvy); pin(a.frad); pin(a.fmax); pin(a.fprefx); pin(a.fprefy);
+  pin(a.tile);
   return a;
 }
 
@@ -523,14 +556,8 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
     *A.arrival = h.arrival;
     float prefx, prefy;  // the float tile entry (store_tile), through the pinned addresses
     orca_pref_velocity(h.px, h.py, h.gx, h.gy, prefx, prefy);
-    *A.fpx = (float)h.px;
-    *A.fpy = (float)h.py;
-    *A.fvx = (float)h.vx;
-    *A.fvy = (float)h.vy;
-    *A.frad = (float)(h.rad + 0.01 + p.orca_safety_space);
-    *A.fmax = (float)h.vpref;
-    *A.fprefx = prefx;
-    *A.fprefy = prefy;
+    A.tile[0] = make_float4((float)h.px, (float)h.py, (float)h.vx, (float)h.vy);
+    A.tile[1] = make_float4((float)(h.rad + 0.01 + p.orca_safety_space), (float)h.vpref, prefx, prefy);
   }
   // ... or, after a terminal step under auto-reset, the env's next scene from the pool: every
   // per-scene field (ragged human count, goals, radii, static rows, map), time 0.  Rare path: its
@@ -549,7 +576,8 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
     if (live) {
       store_tile(p, s, m.k, npx, npy, nvx, nvy, ngx, ngy, nrad, nvp);
     } else {
-      *A.fpx = 0; *A.fpy = 0; *A.fvx = 0; *A.fvy = 0; *A.frad = 0; *A.fmax = 0; *A.fprefx = 0; *A.fprefy = 0;
+      A.tile[0] = make_float4(0, 0, 0, 0);
+      A.tile[1] = make_float4(0, 0, 0, 0);
     }
     if (m.i < S) {
       s.spx[m.ee * S + m.i] = pre.spx;
@@ -636,9 +664,9 @@ __global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState
 //                  the rest are ORCA waves -> hact.  Both read only pre-step state, so the
 //                  service work hides behind the ORCA waves.
 //   phase2_kernel  service_commit from hact.
-template <int GS>
+template <int GS, int K>
 __global__ __launch_bounds__(EBC_WAVE) void phase1_kernel(EbcParams p_in, DevState s_in, StepIO io_in, int env_blocks) {
-  __shared__ __align__(16) unsigned char scratch[EBC_ORCA_LDS];
+  __shared__ __align__(16) unsigned char scratch[OrcaLds<GS, K>::BYTES];
   const int lane = threadIdx.x;
   if ((int)blockIdx.x >= env_blocks) {
     constexpr int HPW = EBC_WAVE / GS;
@@ -646,12 +674,12 @@ __global__ __launch_bounds__(EBC_WAVE) void phase1_kernel(EbcParams p_in, DevSta
     // 32-bit index math (E * N < 2^31 is checked at create): a 64-bit divide is ~100 instructions
     const unsigned hh = (unsigned)(blockIdx.x - env_blocks) * HPW + group;
     const unsigned N = (unsigned)s_in.N;
-    const bool h_ok = hh < (unsigned)s_in.E * N;
-    const int e = h_ok ? (int)(hh / N) : 0;
-    const int i = h_ok ? (int)(hh - (unsigned)e * N) : 0;
+    const bool h_ok = group < HPW && hh < (unsigned)s_in.E * N;  // lanes past HPW * GS idle
+    int e, i;
+    split_human(s_in, hh, h_ok, e, i);
     float ox, oy;
     bool human_ok;
-    orca_wave<GS>(p_in, s_in, h_ok, e, i, scratch, ox, oy, human_ok);
+    orca_wave<GS, K>(p_in, s_in, h_ok, e, i, scratch, ox, oy, human_ok);
     if (h_ok && j == 0) {
       s_in.hact[(size_t)hh * 2] = human_ok ? (double)ox : 0.0;
       s_in.hact[(size_t)hh * 2 + 1] = human_ok ? (double)oy : 0.0;

@@ -43,7 +43,7 @@ struct Handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   bool has_reset = false;
-  int orca_gs = 16;  // lanes per human of the ORCA waves (8 / 16 / 32)
+  int orca_gs = 16;  // lanes per human of the ORCA waves
   std::vector<void *> pool_allocs;   // pool arrays (re-allocated by ebc_set_scene_pool)
   uint64_t *pool_grid_alloc = nullptr;
   // staging for host-location calls
@@ -127,11 +127,21 @@ int orca_blocks(const Handle *h) {
 
 int launch_orca(Handle *h) {
   const int blocks = orca_blocks(h);
-#define OK_(GS) hipLaunchKernelGGL((ebc::orca_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s)
+#define OK_(GS, K) hipLaunchKernelGGL((ebc::orca_kernel<GS, K>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s)
   switch (h->orca_gs) {
-    case 8: OK_(8); break;
-    case 16: OK_(16); break;
-    default: OK_(32); break;
+    case 2: OK_(2, 1); break;
+    case 3: OK_(3, 1); break;
+    case 4: OK_(4, 1); break;
+    case 5: OK_(5, 1); break;
+    case 6: OK_(6, 1); break;
+    case 7: OK_(7, 1); break;
+    case 8: OK_(8, 1); break;
+    case 9: OK_(9, 1); break;
+    case 10: OK_(10, 1); break;
+    case 12: OK_(12, 1); break;
+    case 16: OK_(16, 1); break;
+    case 21: OK_(21, 1); break;
+    default: OK_(32, 1); break;
   }
 #undef OK_
   HIP_TRY(hipGetLastError());
@@ -154,11 +164,21 @@ int launch_orca_step(Handle *h, const StepIO &io) {
   const int epb = EBC_WAVE / h->s.N;
   const int env_blocks = (h->s.E + epb - 1) / epb;
   const int blocks = env_blocks + orca_blocks(h);
-#define P1_(GS) hipLaunchKernelGGL((ebc::phase1_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, env_blocks)
+#define P1_(GS, K) hipLaunchKernelGGL((ebc::phase1_kernel<GS, K>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, env_blocks)
   switch (h->orca_gs) {
-    case 8: P1_(8); break;
-    case 16: P1_(16); break;
-    default: P1_(32); break;
+    case 2: P1_(2, 1); break;
+    case 3: P1_(3, 1); break;
+    case 4: P1_(4, 1); break;
+    case 5: P1_(5, 1); break;
+    case 6: P1_(6, 1); break;
+    case 7: P1_(7, 1); break;
+    case 8: P1_(8, 1); break;
+    case 9: P1_(9, 1); break;
+    case 10: P1_(10, 1); break;
+    case 12: P1_(12, 1); break;
+    case 16: P1_(16, 1); break;
+    case 21: P1_(21, 1); break;
+    default: P1_(32, 1); break;
   }
 #undef P1_
   HIP_TRY(hipGetLastError());
@@ -364,13 +384,23 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   s.N = max_humans;
   s.S = max_static;
   s.G = G;
+  // rvo2 holds these as floats (Agent.cpp: invTimeHorizon, invTimeStep, rangeSq)
+  s.inv_time_horizon = 1.0f / params->orca_time_horizon;
+  s.inv_time_step = 1.0f / (float)params->time_step;
+  s.range_sq = params->orca_neighbor_dist * params->orca_neighbor_dist;
+  {  // h / N for h < 2^31 as mulhi(h, magic) >> shift (N >= 2; N == 1 is the identity)
+    unsigned sh = 0;
+    while ((1u << sh) < (unsigned)max_humans) ++sh;
+    s.n_magic = max_humans > 1 ? (unsigned)((1ull << (31 + sh)) / (unsigned)max_humans + 1) : 0;
+    s.n_shift = max_humans > 1 ? sh - 1 : 0;
+  }
   const size_t EN = (size_t)n_envs * max_humans, ES = (size_t)n_envs * (max_static ? max_static : 1);
   int rc = EBC_OK;
 #define A_(field, cnt) if (rc == EBC_OK) rc = dev_alloc(h, &s.field, (cnt))
   A_(n_humans, n_envs); A_(px, EN); A_(py, EN); A_(vx, EN); A_(vy, EN); A_(gx, EN); A_(gy, EN);
   A_(radius, EN); A_(v_pref, EN); A_(type, EN); A_(n_static, n_envs); A_(spx, ES); A_(spy, ES);
-  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN); A_(fpx, EN); A_(fpy, EN); A_(fvx, EN); A_(fvy, EN); A_(frad, EN);
-  A_(fmax, EN); A_(fprefx, EN); A_(fprefy, EN);
+  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN);
+  A_(tile, EN * 2);
   A_(done, n_envs); A_(hact, EN * 2);
 #undef A_
   if (rc == EBC_OK) rc = dev_alloc(h, &s.pool.cursor, n_envs);
@@ -388,9 +418,16 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   }
   h->stream = h->own_stream;
   {
-    // ORCA role: the smallest group of 8 / 16 / 32 / 64 lanes that holds a human's "others"
     const int others = max_humans - 1 + (params->robot_visible ? 1 : 0);
-    h->orca_gs = others <= 8 ? 8 : others <= 16 ? 16 : 32;
+    // lanes per human = its number of others, rounded up to a size that is instantiated and never
+    // to one that fits fewer humans in a wave (64 / GS): 9 others -> 9 lanes, 7 humans per wave
+    static const int sizes[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32};
+    for (int g : sizes)
+      if (g >= others) { h->orca_gs = g; break; }
+    const char *force = getenv("EBCSIM_ORCA_GROUP");  // measurements only: a larger group size
+    if (force && atoi(force) >= h->orca_gs)
+      for (int g : sizes)
+        if (g >= atoi(force)) { h->orca_gs = g; break; }
   }
   *handle_out = h;
   return EBC_OK;
