@@ -3,15 +3,14 @@
 // One env.step (simulator/env.py:388-466) = robot-side "service" work (lane per human: robot
 // action, collisions, reward, then human update + observation) plus the humans' ORCA velocities
 // (GS lanes per human, ebc_orca_group.h, over the float tile the previous step left in HBM).
-//   phase1_kernel<GS,K> + phase2_kernel<T>   ORCA humans, two launches: a heterogeneous grid of
-//                              one-wave workgroups (service_env waves at full lane use beside
-//                              ORCA waves; both read only pre-step state), then service_commit.
+//   orca_step_kernel<GS,T>     ORCA humans, one launch of one-wave workgroups in four roles
+//                              (ENV, ORCA, ROWS, STATE) that meet through mailbox words.
 //   step_kernel<POLICY,T>      humans on the linear policy or with supplied / cached velocities:
 //                              one launch, service_env + service_commit in the same wave.
 // (A fused single-launch ORCA step -- service wave + ORCA waves per workgroup with an LDS
 // hand-off -- was built and measured: never faster than the split form on MI355X once the
 // service chain was cut down, and 1.6x slower at 4096 x 10; see DESIGN.md.)
-//   orca_kernel<GS,K>   ORCA alone -> hact (look-ahead prelude)
+//   orca_kernel<GS>     ORCA alone -> hact (look-ahead prelude)
 //   lookahead_kernel<T> the |A|-way onestep_lookahead sweep (multi_human_rl.py:38-61).
 //
 // HBM layout: struct-of-arrays [E][N] per human field (lane = e*N + i -> contiguous wave
@@ -22,6 +21,7 @@
 #include "ebc_orca_group.h"
 
 namespace ebc {
+
 
 // Scenes an env restarts from under EBC_FLAG_AUTO_RESET, in the same SoA layout as the state.
 // Slots [0, E) are the envs' own ebc_reset scenes; slots [E, E + P) a host-generated pool installed
@@ -54,7 +54,15 @@ struct DevState {
   double *time;   // [E] global_time
   double *arrival;
   uint8_t *done;  // terminal flag of the last step
-  double *hact;   // [E][N][2] human velocities: ORCA role, ebc_set_human_actions, or look-ahead cache
+  double *hact;   // [E][N][2] human velocities: ebc_set_human_actions, or the look-ahead cache
+  // Mailboxes of the fused ORCA step (orca_step_kernel).  A word is data and "ready" flag at once:
+  // the producer stores a value that is never EMPTY, the consumer polls, takes it and puts EMPTY
+  // back, so every launch starts with every box empty.
+  unsigned long long *vel_state;  // [E][N] ORCA velocity (two floats) for the STATE role
+  unsigned long long *vel_rows;   // [E][N] the same for the ROWS role
+  unsigned *env_done;             // [E] ENV -> STATE: 1 + done
+  unsigned *rows_loaded;          // [E] ROWS -> STATE: pre-step state has been read (1)
+  unsigned *fault;                // [1] a poll gave up (protocol broken); ebc_synchronize reports it
   ScenePool pool;  // where auto-reset takes an env's next scene from
   // what rvo2 would hold for the current state (float), one 32-byte record per human slot:
   // tile[2k] = (position, velocity), tile[2k + 1] = (radius + 0.01 + safety, maxSpeed, preferred
@@ -64,6 +72,9 @@ struct DevState {
   float inv_time_horizon, inv_time_step, range_sq;
   unsigned n_magic, n_shift;
 };
+
+#define EBC_SLOT_EMPTY 0xFFFFFFFFFFFFFFFFull  // two all-ones NaNs: no arithmetic result
+#define EBC_SPIN_LIMIT (1u << 22)               // polls before a consumer gives up (~1 s)
 
 struct StepIO {
   const double *robot_action;
@@ -117,38 +128,44 @@ __global__ __launch_bounds__(256) void tile_kernel(EbcParams p, DevState s) {
 // (env.py:396-402): the humans before and after it, then the robot when it is visible.
 // `scratch` = this wave's private LDS (EBC_ORCA_LDS bytes).  Returns the group's velocity in
 // every lane of the group.
-// LDS of one ORCA wave: per group its distances and two line arrays.  64 / GS groups hold humans;
-// when GS does not divide 64 the left-over lanes form one more (idle) group with its own scratch.
-template <int GS, int K>
+// LDS of one ORCA wave: per group its distances and three line-sized arrays (lines, segments,
+// projected lines).  64 / GS groups hold humans; when GS does not divide 64 the left-over lanes
+// form one more (idle) group with its own scratch.
+template <int GS>
 struct OrcaLds {
-  using Sh = OrcaShape<GS, K>;
+  using Sh = OrcaShape<GS>;
   static constexpr int HPW = EBC_WAVE / GS;
   static constexpr int GROUPS = (EBC_WAVE + GS - 1) / GS;
   static constexpr int DIST = GROUPS * Sh::DIST * 4;
-  static constexpr int BYTES = DIST + 2 * GROUPS * Sh::LINES * 16;
+  static constexpr int BYTES = DIST + 3 * GROUPS * Sh::LINES * 16;
 };
 
-template <int GS, int K>
+template <int GS>
 __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s, bool h_ok, int e, int i,
                                           unsigned char *scratch, float &ox, float &oy, bool &human_ok) {
-  using L = OrcaLds<GS, K>;
+  using L = OrcaLds<GS>;
   float *dist_lds = reinterpret_cast<float *>(scratch);
   float4 *lines_lds = reinterpret_cast<float4 *>(scratch + L::DIST);
-  float4 *proj_lds = lines_lds + L::GROUPS * L::Sh::LINES;
+  float4 *segs_lds = lines_lds + L::GROUPS * L::Sh::LINES;
+  float4 *proj_lds = segs_lds + L::GROUPS * L::Sh::LINES;
   const int N = s.N;
   const int lane = threadIdx.x & (EBC_WAVE - 1);
   const int group = lane / GS;
-  const int j = lane - group * GS;
+  const int j = lane - group * GS;  // "other" index in ob order
   const int n = h_ok ? s.n_humans[e] : 0;
   human_ok = h_ok && i < n;
   const size_t base = (size_t)e * N;
   // tile loads do not wait for n_humans: indices are clamped into the env's row, validity is
   // decided afterwards (padded slots hold zeros)
   const size_t ks = base + i;
+  const int oj = j < i ? j : j + 1;  // humans before / after this one
+  const size_t ko = base + (oj < N ? oj : N - 1);
   float posx = 0, posy = 0, velx = 0, vely = 0, radius = 0, maxSpeed = 0, prefx = 0, prefy = 0;
-  float opx[K], opy[K], ovx[K], ovy[K], orad[K];
+  float opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
   if (h_ok) {
     const float4 a = s.tile[2 * ks], b = s.tile[2 * ks + 1];
+    const float4 c = s.tile[2 * ko];
+    orad = s.tile[2 * ko + 1].x;
     posx = a.x;
     posy = a.y;
     velx = a.z;
@@ -157,41 +174,25 @@ __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s,
     maxSpeed = b.y;
     prefx = b.z;
     prefy = b.w;
-  }
-#pragma unroll
-  for (int q = 0; q < K; ++q) {
-    const int item = q * GS + j;             // "other" index in ob order
-    const int oj = item < i ? item : item + 1;  // humans before / after this one
-    const size_t ko = base + (oj < N ? oj : N - 1);
-    opx[q] = opy[q] = ovx[q] = ovy[q] = orad[q] = 0.0f;
-    if (h_ok) {
-      const float4 a = s.tile[2 * ko];
-      opx[q] = a.x;
-      opy[q] = a.y;
-      ovx[q] = a.z;
-      ovy[q] = a.w;
-      orad[q] = s.tile[2 * ko + 1].x;
-    }
+    opx = c.x;
+    opy = c.y;
+    ovx = c.z;
+    ovy = c.w;
   }
   const int n_others = human_ok ? (n - 1 + (p.robot_visible ? 1 : 0)) : 0;
-  bool valid[K];
-#pragma unroll
-  for (int q = 0; q < K; ++q) {
-    const int item = q * GS + j;
-    valid[q] = item < n_others;
-    if (p.robot_visible && valid[q] && item == n - 1) {  // the robot, last in ob (env.py:401-402)
-      const double *rb = s.robot + (size_t)e * 9;
-      opx[q] = (float)rb[0];
-      opy[q] = (float)rb[1];
-      ovx[q] = (float)rb[2];
-      ovy[q] = (float)rb[3];
-      orad[q] = (float)(rb[4] + 0.01 + p.orca_safety_space);
-    }
+  const bool valid = j < n_others;
+  if (p.robot_visible && valid && j == n - 1) {  // the robot, last in ob (env.py:401-402)
+    const double *rb = s.robot + (size_t)e * 9;
+    opx = (float)rb[0];
+    opy = (float)rb[1];
+    ovx = (float)rb[2];
+    ovy = (float)rb[3];
+    orad = (float)(rb[4] + 0.01 + p.orca_safety_space);
   }
-  orca_group<GS, K>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy,
-                    ovx, ovy, orad, dist_lds + group * L::Sh::DIST, lines_lds + group * L::Sh::LINES,
-                    proj_lds + group * L::Sh::LINES, N - 1 + (p.robot_visible ? 1 : 0), s.range_sq,
-                    s.inv_time_horizon, s.inv_time_step, ox, oy);
+  orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy, ovx,
+                 ovy, orad, dist_lds + group * L::Sh::DIST, lines_lds + group * L::Sh::LINES,
+                 segs_lds + group * L::Sh::LINES, proj_lds + group * L::Sh::LINES,
+                 N - 1 + (p.robot_visible ? 1 : 0), s.range_sq, s.inv_time_horizon, s.inv_time_step, ox, oy);
 }
 
 // (env, slot) of flat human index h < E * N without the ~20-instruction integer divide
@@ -203,10 +204,11 @@ __device__ __forceinline__ void split_human(const DevState &s, unsigned h, bool 
 }
 
 // ORCA alone -> s.hact: the prelude of a look-ahead sweep (the following step re-uses it).
-template <int GS, int K>
+template <int GS>
 __global__ __launch_bounds__(EBC_WAVE) void orca_kernel(EbcParams p, DevState s) {
+  const WaveTrace wt(0);
   constexpr int HPW = EBC_WAVE / GS;
-  __shared__ __align__(16) unsigned char scratch[OrcaLds<GS, K>::BYTES];
+  __shared__ __align__(16) unsigned char scratch[OrcaLds<GS>::BYTES];
   const int group = threadIdx.x / GS, j = threadIdx.x - group * GS;
   const unsigned h = (unsigned)blockIdx.x * HPW + group;
   const unsigned N = (unsigned)s.N;
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(EBC_WAVE) void orca_kernel(EbcParams p, DevState s)
   split_human(s, h, h_ok, e, i);
   float ox, oy;
   bool human_ok;
-  orca_wave<GS, K>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
+  orca_wave<GS>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
   if (h_ok && j == 0) {
     s.hact[(size_t)h * 2] = human_ok ? (double)ox : 0.0;  // getAgentVelocity -> Python float
     s.hact[(size_t)h * 2 + 1] = human_ok ? (double)oy : 0.0;
@@ -315,6 +317,7 @@ struct CommitPre {
   int type, n_humans, n_static;
 };
 
+template <bool WITH_ROBOT = true>
 __device__ __forceinline__ CommitPre preload_commit(const DevState &s, const StepIO &io, const LaneMap &m) {
   CommitPre c;
 #pragma unroll
@@ -346,7 +349,7 @@ __device__ __forceinline__ CommitPre preload_commit(const DevState &s, const Ste
         c.spx = P.spx[q]; c.spy = P.spy[q]; c.srad = P.sradius[q];
       }
     }
-    if (m.leader) {
+    if (WITH_ROBOT && m.leader) {
 #pragma unroll
       for (int q = 0; q < 9; ++q) c.robot[q] = P.robot[(size_t)c.cursor * 9 + q];
     }
@@ -381,6 +384,7 @@ struct CommitAddr {
   float4 *tile;
   float *obs;
 };
+template <bool PIN = true>
 __device__ __forceinline__ CommitAddr commit_addr(const DevState &s, const StepIO &io, const LaneMap &m) {
   CommitAddr a;
   a.px = s.px + m.k; a.py = s.py + m.k; a.vx = s.vx + m.k; a.vy = s.vy + m.k;
@@ -391,10 +395,39 @@ __device__ __forceinline__ CommitAddr commit_addr(const DevState &s, const StepI
   a.ob = io.ob ? io.ob + m.ee * (size_t)(s.N + s.S) * 5 : nullptr;
   a.obs = io.obs_rotated;  // row offset depends on T: added by the caller
   a.tile = s.tile + 2 * m.k;
-  pin(a.px); pin(a.py); pin(a.vx); pin(a.vy); pin(a.arrival); pin(a.robot); pin(a.time);
-  pin(a.human_action); pin(a.ob); pin(a.obs);
-  pin(a.tile);
+  if (PIN) {
+    pin(a.px); pin(a.py); pin(a.vx); pin(a.vy); pin(a.arrival); pin(a.robot); pin(a.time);
+    pin(a.human_action); pin(a.ob); pin(a.obs);
+    pin(a.tile);
+  }
   return a;
+}
+
+// The robot's action for this step (its policy, or the caller's) — env.py:388-392.
+__device__ __forceinline__ void robot_action(const StepIO &io, size_t ee, const double *rb, double &a0, double &a1) {
+  if (io.robot_policy == EBC_ROBOT_LINEAR) {
+    linear_policy(rb[0], rb[1], rb[5], rb[6], rb[7], a0, a1);
+  } else {
+    a0 = io.robot_action[2 * ee];
+    a1 = io.robot_action[2 * ee + 1];
+  }
+}
+// Agent.step for the robot (agent.py:202-228): rb becomes the next state.  It depends on the action
+// alone, so every role that needs the robot's next state works it out itself instead of waiting
+// for the ENV role.
+__device__ __forceinline__ void robot_advance(const EbcParams &p, double *rb, double a0, double a1) {
+  double nx, ny;
+  robot_next_position(rb, p.robot_kinematics, a0, a1, p.time_step, nx, ny);
+  rb[0] = nx;
+  rb[1] = ny;
+  if (p.robot_kinematics == EBC_HOLONOMIC) {
+    rb[2] = a0;
+    rb[3] = a1;
+  } else {
+    rb[8] = py_mod(rb[8] + a1, 2 * M_PI);
+    rb[2] = a0 * cos(rb[8]);
+    rb[3] = a0 * sin(rb[8]);
+  }
 }
 
 // Leader lanes return the step's done flag and leave the robot's NEXT state in rb.
@@ -478,6 +511,77 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
   return ro.done;
 }
 
+// The state the next step will see: the moved humans and their float tile entries, or — after a
+// terminal step under auto-reset — the env's next scene.
+template <bool WITH_ROBOT = true>
+__device__ __forceinline__ void commit_state_tail(const EbcParams &p, const DevState &s, const LaneMap &m,
+                                                  const HumanRegs &h, const CommitPre &pre,
+                                                  const CommitAddr &A, bool restore, bool restore_later) {
+  const int N = s.N, S = s.S;
+  // the humans: the moved state ...
+  if (m.active && !restore && !restore_later) {
+    *A.px = h.px;
+    *A.py = h.py;
+    *A.vx = h.vx;
+    *A.vy = h.vy;
+    *A.arrival = h.arrival;
+    float prefx, prefy;  // the float tile entry (store_tile), through the pinned addresses
+    orca_pref_velocity(h.px, h.py, h.gx, h.gy, prefx, prefy);
+    A.tile[0] = make_float4((float)h.px, (float)h.py, (float)h.vx, (float)h.vy);
+    A.tile[1] = make_float4((float)(h.rad + 0.01 + p.orca_safety_space), (float)h.vpref, prefx, prefy);
+  }
+  EBC_MARK(4);
+  // ... or, after a terminal step under auto-reset, the env's next scene from the pool: every
+  // per-scene field (ragged human count, goals, radii, static rows, map), time 0.  Rare path: its
+  // loads sit behind the step's stores on purpose.
+  if (restore) {
+    const ScenePool &P = s.pool;
+    const int n_new = pre.n_humans;
+    const bool live = m.i < n_new;
+    const double npx = live ? pre.px : 0.0, npy = live ? pre.py : 0.0;
+    const double nvx = live ? pre.vx : 0.0, nvy = live ? pre.vy : 0.0;
+    const double ngx = live ? pre.gx : 0.0, ngy = live ? pre.gy : 0.0;
+    const double nrad = live ? pre.rad : 0.0, nvp = live ? pre.vpref : 0.0;
+    *A.px = npx; *A.py = npy; *A.vx = nvx; *A.vy = nvy; *A.arrival = 0.0;
+    s.gx[m.k] = ngx; s.gy[m.k] = ngy; s.radius[m.k] = nrad; s.v_pref[m.k] = nvp;
+    s.type[m.k] = live ? (uint8_t)pre.type : (uint8_t)0;
+    if (live) {
+      store_tile(p, s, m.k, npx, npy, nvx, nvy, ngx, ngy, nrad, nvp);
+    } else {
+      A.tile[0] = make_float4(0, 0, 0, 0);
+      A.tile[1] = make_float4(0, 0, 0, 0);
+    }
+    if (m.i < S) {
+      s.spx[m.ee * S + m.i] = pre.spx;
+      s.spy[m.ee * S + m.i] = pre.spy;
+      s.sradius[m.ee * S + m.i] = pre.srad;
+    }
+    for (int q = m.i + N; q < S; q += N) {  // more static rows than humans: late loads (rare)
+      const size_t c = (size_t)pre.cursor * S + q;
+      s.spx[m.ee * S + q] = P.spx[c];
+      s.spy[m.ee * S + q] = P.spy[c];
+      s.sradius[m.ee * S + q] = P.sradius[c];
+    }
+    if (m.leader) {
+      s.n_humans[m.ee] = n_new;
+      if (S) s.n_static[m.ee] = pre.n_static;
+      s.grid_scene[m.ee] = pre.cursor;
+      if (WITH_ROBOT) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) A.robot[q] = pre.robot[q];
+      } else {  // the caller did not hold the restart robot in registers: copy it now
+        const double *src = P.robot + (size_t)pre.cursor * 9;
+        for (int q = 0; q < 9; ++q) A.robot[q] = src[q];
+      }
+      *A.time = 0.0;
+      if (P.P > 0) {  // walk the custom pool; without one the env keeps restarting from its own slot
+        int nxt = pre.cursor - s.E + P.stride;
+        P.cursor[m.ee] = s.E + (nxt >= P.P ? nxt % P.P : nxt);
+      }
+    }
+  }
+}
+
 // rbn: the robot's next state (in registers); (ax, ay): this human's velocity.
 template <int T>
 __device__ __forceinline__ void service_commit(const EbcParams &p, const DevState &s, const StepIO &io,
@@ -496,8 +600,10 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
     ax = 0;
     ay = 0;
   }
+  EBC_MARK(1);
   const RotFrame f = rot_frame(rbn, p.rotate_unicycle);
   pin_pool(pre);  // first store of the commit below
+  EBC_MARK(2);
   if (m.leader && !restore) {  // the robot: the moved state (the restart scene: restore path)
 #pragma unroll
     for (int c = 0; c < 9; ++c) A.robot[c] = rbn[c];
@@ -547,62 +653,8 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
       }
     }
   }
-  // the humans: the moved state ...
-  if (m.active && !restore) {
-    *A.px = h.px;
-    *A.py = h.py;
-    *A.vx = h.vx;
-    *A.vy = h.vy;
-    *A.arrival = h.arrival;
-    float prefx, prefy;  // the float tile entry (store_tile), through the pinned addresses
-    orca_pref_velocity(h.px, h.py, h.gx, h.gy, prefx, prefy);
-    A.tile[0] = make_float4((float)h.px, (float)h.py, (float)h.vx, (float)h.vy);
-    A.tile[1] = make_float4((float)(h.rad + 0.01 + p.orca_safety_space), (float)h.vpref, prefx, prefy);
-  }
-  // ... or, after a terminal step under auto-reset, the env's next scene from the pool: every
-  // per-scene field (ragged human count, goals, radii, static rows, map), time 0.  Rare path: its
-  // loads sit behind the step's stores on purpose.
-  if (restore) {
-    const ScenePool &P = s.pool;
-    const int n_new = pre.n_humans;
-    const bool live = m.i < n_new;
-    const double npx = live ? pre.px : 0.0, npy = live ? pre.py : 0.0;
-    const double nvx = live ? pre.vx : 0.0, nvy = live ? pre.vy : 0.0;
-    const double ngx = live ? pre.gx : 0.0, ngy = live ? pre.gy : 0.0;
-    const double nrad = live ? pre.rad : 0.0, nvp = live ? pre.vpref : 0.0;
-    *A.px = npx; *A.py = npy; *A.vx = nvx; *A.vy = nvy; *A.arrival = 0.0;
-    s.gx[m.k] = ngx; s.gy[m.k] = ngy; s.radius[m.k] = nrad; s.v_pref[m.k] = nvp;
-    s.type[m.k] = live ? (uint8_t)pre.type : (uint8_t)0;
-    if (live) {
-      store_tile(p, s, m.k, npx, npy, nvx, nvy, ngx, ngy, nrad, nvp);
-    } else {
-      A.tile[0] = make_float4(0, 0, 0, 0);
-      A.tile[1] = make_float4(0, 0, 0, 0);
-    }
-    if (m.i < S) {
-      s.spx[m.ee * S + m.i] = pre.spx;
-      s.spy[m.ee * S + m.i] = pre.spy;
-      s.sradius[m.ee * S + m.i] = pre.srad;
-    }
-    for (int q = m.i + N; q < S; q += N) {  // more static rows than humans: late loads (rare)
-      const size_t c = (size_t)pre.cursor * S + q;
-      s.spx[m.ee * S + q] = P.spx[c];
-      s.spy[m.ee * S + q] = P.spy[c];
-      s.sradius[m.ee * S + q] = P.sradius[c];
-    }
-    if (m.leader) {
-      s.n_humans[m.ee] = n_new;
-      if (S) s.n_static[m.ee] = pre.n_static;
-      s.grid_scene[m.ee] = pre.cursor;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) A.robot[q] = pre.robot[q];
-      *A.time = 0.0;
-      if (P.P > 0) {  // walk the custom pool; without one the env keeps restarting from its own slot
-        int nxt = pre.cursor - s.E + P.stride;
-        P.cursor[m.ee] = s.E + (nxt >= P.P ? nxt % P.P : nxt);
-      }
-    }
-  }
+  EBC_MARK(3);
+  commit_state_tail(p, s, m, h, pre, A, restore, false);
 }
 
 __device__ __forceinline__ void load_robot(const DevState &s, const LaneMap &m, double rb[9]) {
@@ -615,6 +667,7 @@ __device__ __forceinline__ void load_robot(const DevState &s, const LaneMap &m, 
 // launch of one-wave workgroups, service_env then service_commit in the same wave.
 template <int POLICY, int T>
 __global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState s_in, StepIO io_in) {
+  const WaveTrace wt(1);
   const int lane = threadIdx.x;
   __shared__ ArgBlock args;
   __shared__ double sh_rbn[EBC_WAVE][9];
@@ -658,87 +711,294 @@ __global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState
   service_commit<T>(p, s, io, m, h, pre, A, rbn, io.auto_reset && done_flag, gtime + p.time_step, ax, ay);
 }
 
-// ORCA step: TWO launches.
-//   phase1_kernel  heterogeneous grid of one-wave workgroups: [0, env_blocks) run service_env
-//                  (6 envs per wave at N = 10: the serial robot-side work at full lane use),
-//                  the rest are ORCA waves -> hact.  Both read only pre-step state, so the
-//                  service work hides behind the ORCA waves.
-//   phase2_kernel  service_commit from hact.
-template <int GS, int K>
-__global__ __launch_bounds__(EBC_WAVE) void phase1_kernel(EbcParams p_in, DevState s_in, StepIO io_in, int env_blocks) {
-  __shared__ __align__(16) unsigned char scratch[OrcaLds<GS, K>::BYTES];
-  const int lane = threadIdx.x;
-  if ((int)blockIdx.x >= env_blocks) {
-    constexpr int HPW = EBC_WAVE / GS;
-    const int group = lane / GS, j = lane - group * GS;
-    // 32-bit index math (E * N < 2^31 is checked at create): a 64-bit divide is ~100 instructions
-    const unsigned hh = (unsigned)(blockIdx.x - env_blocks) * HPW + group;
-    const unsigned N = (unsigned)s_in.N;
-    const bool h_ok = group < HPW && hh < (unsigned)s_in.E * N;  // lanes past HPW * GS idle
-    int e, i;
-    split_human(s_in, hh, h_ok, e, i);
-    float ox, oy;
-    bool human_ok;
-    orca_wave<GS, K>(p_in, s_in, h_ok, e, i, scratch, ox, oy, human_ok);
-    if (h_ok && j == 0) {
-      s_in.hact[(size_t)hh * 2] = human_ok ? (double)ox : 0.0;
-      s_in.hact[(size_t)hh * 2 + 1] = human_ok ? (double)oy : 0.0;
+// ORCA step: ONE launch of one-wave workgroups in four roles (orca_step_kernel).
+//
+//   ENV    service_env (6 envs per wave at N = 10): the robot side of the step, reward / done /
+//          info.  The longest dependent chain, so these blocks come first.    -> env_done
+//   ORCA   64 / GS humans per wave                                            -> vel_state, vel_rows
+//   ROWS   lane = observation row slot: reads the pre-step state, tells STATE so (rows_loaded),
+//          takes the human's velocity from vel_rows, emits the raw and the rotated row
+//   STATE  lane = human slot: takes vel_state and env_done, moves the humans, writes the state
+//          and float tile of the next step (or the restart scene)
+//
+// Everything in a step is local to an env, so the roles meet through per-env / per-human mailbox
+// words in HBM instead of a second launch: an env's rows and state are written as soon as ITS
+// humans and ITS robot-side work are done, while the slowest ORCA waves of the launch (the
+// humans deep in linearProgram3) are still running.  Consumers (ROWS, STATE) only wait for
+// workgroups of LOWER index; the dispatcher starts workgroups in index order and producers wait
+// for nothing, so every wait ends.  A poll that exceeds EBC_SPIN_LIMIT gives up and raises
+// DevState::fault rather than hang the device.
+struct StepGrid {
+  unsigned env_blocks, orca_blocks, rows_blocks;  // then env_blocks STATE blocks
+  unsigned rows_epw;                               // envs per ROWS wave (1 when N + S > 64)
+};
+
+// wave-wide: returns once every lane with `need` has found its word non-empty (or gave up)
+template <typename W>
+__device__ __forceinline__ W mailbox_wait(W *box, bool need, W empty, unsigned *fault) {
+  W v = empty;
+  bool waiting = need;
+  for (unsigned spins = 0;; ++spins) {
+    if (waiting) {
+      v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      waiting = v == empty;
     }
-    return;
+    if (!__any(waiting)) break;
+    if (spins > EBC_SPIN_LIMIT) {
+      if (waiting) atomicOr(fault, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
   }
-  __shared__ ArgBlock args;
-  stage_args(&args.p, p_in, lane);
-  stage_args(&args.s, s_in, lane);
-  stage_args(&args.io, io_in, lane);
+  return v;
+}
+template <typename W>
+__device__ __forceinline__ void mailbox_put(W *box, W v) {
+  __hip_atomic_store(box, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void unpack_velocity(unsigned long long v, double &ax, double &ay) {
+  ax = (double)__uint_as_float((unsigned)v);  // getAgentVelocity -> Python float
+  ay = (double)__uint_as_float((unsigned)(v >> 32));
+}
+
+struct RoleLds {
+  ArgBlock args;
+};
+
+// ---- ENV
+__device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in,
+                                         RoleLds &L, int block, int lane) {
+  stage_args(&L.args.p, p_in, lane);
+  stage_args(&L.args.s, s_in, lane);
+  stage_args(&L.args.io, io_in, lane);
   wave_sync();
-  const EbcParams &p = args.p;
-  const DevState &s = args.s;
-  const StepIO &io = args.io;
+  const EbcParams &p = L.args.p;
+  const DevState &s = L.args.s;
+  const StepIO &io = L.args.io;
   const int epb = EBC_WAVE / s.N;
-  const LaneMap m = lane_map(s, blockIdx.x * epb, epb, lane);
+  const LaneMap m = lane_map(s, block * epb, epb, lane);
   double rb[9];
   load_robot(s, m, rb);
   double gtime = m.env_ok ? s.time[m.ee] : 0.0;
   HumanRegs h = load_human(s, m);
-  pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type); pin(gtime);
+  unsigned *done_box = s.env_done + m.ee;
+  pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type); pin(gtime); pin(done_box);
 #pragma unroll
   for (int q = 0; q < 9; ++q) pin(rb[q]);
-  service_env(p, s, io, m, h, rb, gtime, lane);
-  if (m.leader) {  // the robot's next state waits in scratch for phase 2 (ORCA waves may read s.robot)
-    double *o = s.robot_n + m.ee * 9;
-#pragma unroll
-    for (int c = 0; c < 9; ++c) o[c] = rb[c];
+  const int done = service_env(p, s, io, m, h, rb, gtime, lane);
+  if (m.leader) mailbox_put(done_box, 1u + (unsigned)done);
+}
+
+// ---- ORCA
+template <int GS>
+__device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s, unsigned char *scratch,
+                                          unsigned block, bool rows, int lane) {
+  constexpr int HPW = EBC_WAVE / GS;
+  const int group = lane / GS, j = lane - group * GS;
+  // 32-bit index math (E * N < 2^31 is checked at create)
+  const unsigned hh = block * HPW + group;
+  const bool h_ok = group < HPW && hh < (unsigned)s.E * (unsigned)s.N;  // lanes past HPW * GS idle
+  int e, i;
+  split_human(s, hh, h_ok, e, i);
+  float ox, oy;
+  bool human_ok;
+  orca_wave<GS>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
+  if (h_ok && j == 0) {
+    unsigned long long v = human_ok ? ((unsigned long long)__float_as_uint(oy) << 32) | __float_as_uint(ox) : 0ull;
+    if (v == EBC_SLOT_EMPTY) v = 0x7FC000007FC00000ull;  // not an arithmetic result; keeps the protocol total
+    mailbox_put(s.vel_state + hh, v);
+    if (rows) mailbox_put(s.vel_rows + hh, v);  // a box nobody empties would hold a stale velocity
   }
 }
 
+// ---- ROWS: lane = row slot of an env.  Slots [0, N) are the human slots, [N, N + S) the static
+// slots, so no load waits for n_humans; the ROW a slot emits is: human i < n -> i, static j < ns ->
+// n + j, and the padding rows (zeros) are shared out over the unused slots: human slot i >= n ->
+// ns + i, static slot j >= ns -> N + j.
 template <int T>
-__global__ __launch_bounds__(EBC_WAVE) void phase2_kernel(EbcParams p_in, DevState s_in, StepIO io_in) {
-  const int lane = threadIdx.x;
-  __shared__ ArgBlock args;
-  stage_args(&args.p, p_in, lane);
-  stage_args(&args.s, s_in, lane);
-  stage_args(&args.io, io_in, lane);
+__device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in,
+                                          RoleLds &L, unsigned block, unsigned epw, int lane) {
+  stage_args(&L.args.p, p_in, lane);
+  stage_args(&L.args.s, s_in, lane);
+  stage_args(&L.args.io, io_in, lane);
   wave_sync();
-  const EbcParams &p = args.p;
-  const DevState &s = args.s;
-  const StepIO &io = args.io;
-  const int epb = EBC_WAVE / s.N;
-  const LaneMap m = lane_map(s, blockIdx.x * epb, epb, lane);
-  if (!m.env_ok) return;
-  HumanRegs h = load_human(s, m);
-  CommitPre pre = preload_commit(s, io, m);
-  const CommitAddr A = commit_addr(s, io, m);
-  double gtime = s.time[m.ee];
-  int done_flag = s.done[m.ee];
-  double ax = s.hact[m.k * 2], ay = s.hact[m.k * 2 + 1];
-  double rbn[9];
+  const EbcParams &p = L.args.p;
+  const DevState &s = L.args.s;
+  const StepIO &io = L.args.io;
+  const int N = s.N, S = s.S, R = N + S;
+  const int el = R <= EBC_WAVE ? lane / R : 0;
+  const int first = lane - el * R;
+  const int e = (int)(block * epw) + el;
+  const bool env_ok = el < (int)epw && e < s.E;
+  const size_t ee = env_ok ? (size_t)e : 0;
+  const int stride = R <= EBC_WAVE ? R : EBC_WAVE;  // one pass unless an env has more rows than lanes
+  // the robot's next state, from its pre-step state and this step's action.  Done before the row
+  // loads are issued: nothing here is urgent (the velocities arrive microseconds later) and the
+  // policy's trigonometry would otherwise hold its temporaries beside the row data.
+  double rb[9];
 #pragma unroll
-  for (int c = 0; c < 9; ++c) rbn[c] = s.robot_n[m.ee * 9 + c];
-  pin_loads(h, pre, rbn, gtime);
-  pin(ax);
-  pin(ay);
-  pin(done_flag);
-  service_commit<T>(p, s, io, m, h, pre, A, rbn, io.auto_reset && done_flag, gtime + p.time_step, ax, ay);
+  for (int c = 0; c < 9; ++c) rb[c] = env_ok ? s.robot[ee * 9 + c] : 0.0;
+  {
+    double a0 = 0, a1 = 0;
+    if (env_ok) robot_action(io, ee, rb, a0, a1);
+    robot_advance(p, rb, a0, a1);
+  }
+  const RotFrame f = rot_frame(rb, p.rotate_unicycle);
+  int n = env_ok ? s.n_humans[ee] : 0;
+  int ns = (env_ok && S) ? s.n_static[ee] : 0;
+  for (int slot = first; slot < R; slot += stride) {
+    const bool human = slot < N;
+    const size_t k = ee * N + (human ? slot : 0), q = ee * (size_t)(S ? S : 1) + (human ? 0 : slot - N);
+    double opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
+    int otype = 0;
+    if (env_ok && human) {
+      opx = s.px[k]; opy = s.py[k]; orad = s.radius[k]; otype = s.type[k];
+    } else if (env_ok) {
+      opx = s.spx[q]; opy = s.spy[q]; orad = s.sradius[q]; otype = EBC_ADULT_STATIC;
+    }
+    unsigned long long *vbox = s.vel_rows + k;
+    pin(opx); pin(opy); pin(orad); pin(otype); pin(vbox); pin(n); pin(ns);
+    // every pre-step value this env's rows need is in registers: STATE may overwrite the state
+    if (env_ok && slot + stride >= R && first == 0) mailbox_put(s.rows_loaded + ee, 1u);
+    const bool valid = human ? slot < n : slot - N < ns;
+    const int row = human ? (valid ? slot : ns + slot) : (valid ? n + slot - N : slot);
+    const unsigned long long v = mailbox_wait(vbox, env_ok && human, (unsigned long long)EBC_SLOT_EMPTY, s.fault);
+    if (env_ok && human) mailbox_put(vbox, (unsigned long long)EBC_SLOT_EMPTY);
+    if (env_ok) {
+      if (human && valid) {  // Agent.step (agent.py:202-211)
+        double ax, ay;
+        unpack_velocity(v, ax, ay);
+        opx = opx + ax * p.time_step;
+        opy = opy + ay * p.time_step;
+        ovx = ax;
+        ovy = ay;
+      }
+      if (!valid) opx = opy = ovx = ovy = orad = 0.0;
+      if (io.ob) {
+        double *o = io.ob + (ee * R + row) * 5;
+        o[0] = opx; o[1] = opy; o[2] = ovx; o[3] = ovy; o[4] = orad;
+      }
+      if (io.obs_rotated) {
+        float out[T];
+        if (valid) {
+          rotate_row<T>(f, opx, opy, ovx, ovy, orad, otype, out);
+        } else {
+#pragma unroll
+          for (int c = 0; c < T; ++c) out[c] = 0.0f;
+        }
+        float *o = io.obs_rotated + (ee * R + row) * T;
+#pragma unroll
+        for (int c = 0; c < T; ++c) o[c] = out[c];
+      }
+    }
+  }
+}
+
+// ---- STATE
+__device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in,
+                                           RoleLds &L, int block, bool wait_rows, int lane) {
+  stage_args(&L.args.p, p_in, lane);
+  stage_args(&L.args.s, s_in, lane);
+  stage_args(&L.args.io, io_in, lane);
+  wave_sync();
+  const EbcParams &p = L.args.p;
+  const DevState &s = L.args.s;
+  const StepIO &io = L.args.io;
+  const int epb = EBC_WAVE / s.N;
+  const LaneMap m = lane_map(s, block * epb, epb, lane);
+  // the robot's next state first (see rows_role), then the humans
+  double rb[9];
+  load_robot(s, m, rb);
+  if (m.leader) {
+    double a0, a1;
+    robot_action(io, m.ee, rb, a0, a1);
+    robot_advance(p, rb, a0, a1);
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) pin(rb[q]);
+  double gtime = m.env_ok ? s.time[m.ee] : 0.0;
+  HumanRegs h = load_human(s, m);
+  StepIO io_state = io;  // no observation rows here: CommitPre's static-row preloads stay empty
+  io_state.ob = nullptr;
+  io_state.obs_rotated = nullptr;
+  unsigned long long *vbox = s.vel_state + m.k;
+  unsigned *done_box = s.env_done + m.ee, *loaded_box = s.rows_loaded + m.ee;
+  pin(vbox); pin(done_box); pin(loaded_box);
+  pin(h.px); pin(h.py); pin(h.gx); pin(h.gy); pin(h.rad); pin(h.vpref); pin(h.arrival); pin(gtime);
+  // wait for this wave's humans (every ORCA group of these envs has then read the tile and the
+  // robot), for the envs' robot-side result, and for the ROWS waves to have read the old state
+  const unsigned long long v = mailbox_wait(vbox, m.env_ok, (unsigned long long)EBC_SLOT_EMPTY, s.fault);
+  const unsigned d = mailbox_wait(done_box, m.env_ok, 0u, s.fault);
+  if (wait_rows) mailbox_wait(loaded_box, m.env_ok, 0u, s.fault);
+  if (!m.env_ok) return;
+  mailbox_put(vbox, (unsigned long long)EBC_SLOT_EMPTY);
+  if (m.leader) {
+    mailbox_put(done_box, 0u);
+    if (wait_rows) mailbox_put(loaded_box, 0u);
+  }
+  const bool restore = io.auto_reset && d == 2u;
+  const double tnew = gtime + p.time_step;
+  const CommitAddr A = commit_addr<false>(s, io_state, m);
+  double ax = 0, ay = 0;
+  if (m.active) {  // Agent.step (agent.py:202-211), first arrival (env.py:365-378)
+    unpack_velocity(v, ax, ay);
+    h.px = h.px + ax * p.time_step;
+    h.py = h.py + ay * p.time_step;
+    h.vx = ax;
+    h.vy = ay;
+    if (h.arrival == 0 && norm2(h.px - h.gx, h.py - h.gy) < h.rad) h.arrival = tnew;
+  }
+  if (m.leader && !restore) {  // the robot: the moved state (the restart scene: restore path)
+#pragma unroll
+    for (int c = 0; c < 9; ++c) A.robot[c] = rb[c];
+    *A.time = tnew;
+  }
+  if (A.human_action) {
+    A.human_action[0] = ax;
+    A.human_action[1] = ay;
+  }
+  CommitPre none = {};
+  commit_state_tail(p, s, m, h, none, A, false, restore);
+  // A terminal env under auto-reset takes its next scene now.  Its loads start here (cursor, then
+  // the scene: two round trips): such waves finish later than the rest, but a launch ends with
+  // its slowest ORCA waves, long after most STATE waves, so the restart is seldom what is last.
+  if (__any(restore)) {
+    const CommitPre pre = preload_commit<false>(s, io_state, m);
+    if (restore) commit_state_tail<false>(p, s, m, h, pre, A, true, false);
+  }
+}
+
+#ifndef EBC_STEP_WAVES
+#define EBC_STEP_WAVES 7
+#endif
+template <int GS, int T>
+__global__ __launch_bounds__(EBC_WAVE, EBC_STEP_WAVES) void orca_step_kernel(EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
+  const WaveTrace wt(2);
+  constexpr size_t LDS = sizeof(RoleLds) > (size_t)OrcaLds<GS>::BYTES ? sizeof(RoleLds) : (size_t)OrcaLds<GS>::BYTES;
+  __shared__ __align__(16) unsigned char lds[LDS];
+  RoleLds &L = *reinterpret_cast<RoleLds *>(lds);
+  const int lane = threadIdx.x;
+  unsigned b = blockIdx.x;
+#ifndef EBC_ROLE_MASK  // register-budget experiments: compile a subset of the roles
+#define EBC_ROLE_MASK 15
+#endif
+  if (b < g.env_blocks) {
+    __builtin_amdgcn_s_setprio(3);  // the long dependent chain of the launch
+    if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, lane);
+    return;
+  }
+  b -= g.env_blocks;
+  if (b < g.orca_blocks) {
+    if (EBC_ROLE_MASK & 2) orca_role<GS>(p_in, s_in, lds, b, g.rows_blocks != 0, lane);
+    return;
+  }
+  b -= g.orca_blocks;
+  if (b < g.rows_blocks) {
+    if (EBC_ROLE_MASK & 4) rows_role<T>(p_in, s_in, io_in, L, b, g.rows_epw, lane);
+    return;
+  }
+  b -= g.rows_blocks;
+  if (EBC_ROLE_MASK & 8) state_role(p_in, s_in, io_in, L, (int)b, g.rows_blocks != 0, lane);
 }
 
 // ------------------------------------------------------------------------- observe

@@ -127,21 +127,21 @@ int orca_blocks(const Handle *h) {
 
 int launch_orca(Handle *h) {
   const int blocks = orca_blocks(h);
-#define OK_(GS, K) hipLaunchKernelGGL((ebc::orca_kernel<GS, K>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s)
+#define OK_(GS) hipLaunchKernelGGL((ebc::orca_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s)
   switch (h->orca_gs) {
-    case 2: OK_(2, 1); break;
-    case 3: OK_(3, 1); break;
-    case 4: OK_(4, 1); break;
-    case 5: OK_(5, 1); break;
-    case 6: OK_(6, 1); break;
-    case 7: OK_(7, 1); break;
-    case 8: OK_(8, 1); break;
-    case 9: OK_(9, 1); break;
-    case 10: OK_(10, 1); break;
-    case 12: OK_(12, 1); break;
-    case 16: OK_(16, 1); break;
-    case 21: OK_(21, 1); break;
-    default: OK_(32, 1); break;
+    case 2: OK_(2); break;
+    case 3: OK_(3); break;
+    case 4: OK_(4); break;
+    case 5: OK_(5); break;
+    case 6: OK_(6); break;
+    case 7: OK_(7); break;
+    case 8: OK_(8); break;
+    case 9: OK_(9); break;
+    case 10: OK_(10); break;
+    case 12: OK_(12); break;
+    case 16: OK_(16); break;
+    case 21: OK_(21); break;
+    default: OK_(32); break;
   }
 #undef OK_
   HIP_TRY(hipGetLastError());
@@ -160,34 +160,41 @@ int launch_service(Handle *h, const StepIO &io) {
   return EBC_OK;
 }
 
-int launch_orca_step(Handle *h, const StepIO &io) {
-  const int epb = EBC_WAVE / h->s.N;
-  const int env_blocks = (h->s.E + epb - 1) / epb;
-  const int blocks = env_blocks + orca_blocks(h);
-#define P1_(GS, K) hipLaunchKernelGGL((ebc::phase1_kernel<GS, K>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, env_blocks)
-  switch (h->orca_gs) {
-    case 2: P1_(2, 1); break;
-    case 3: P1_(3, 1); break;
-    case 4: P1_(4, 1); break;
-    case 5: P1_(5, 1); break;
-    case 6: P1_(6, 1); break;
-    case 7: P1_(7, 1); break;
-    case 8: P1_(8, 1); break;
-    case 9: P1_(9, 1); break;
-    case 10: P1_(10, 1); break;
-    case 12: P1_(12, 1); break;
-    case 16: P1_(16, 1); break;
-    case 21: P1_(21, 1); break;
-    default: P1_(32, 1); break;
-  }
-#undef P1_
-  HIP_TRY(hipGetLastError());
+template <int GS>
+int launch_orca_step_gs(Handle *h, const StepIO &io, unsigned blocks, const ebc::StepGrid &g) {
   if (h->T == 17)
-    hipLaunchKernelGGL((ebc::phase2_kernel<17>), dim3(env_blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 17>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, g);
   else
-    hipLaunchKernelGGL((ebc::phase2_kernel<13>), dim3(env_blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io);
+    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 13>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, g);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
+}
+
+int launch_orca_step(Handle *h, const StepIO &io) {
+  const int epb = EBC_WAVE / h->s.N;
+  const int R = h->s.N + h->s.S;
+  ebc::StepGrid g;
+  g.env_blocks = (unsigned)((h->s.E + epb - 1) / epb);
+  g.orca_blocks = (unsigned)orca_blocks(h);
+  g.rows_epw = R <= EBC_WAVE ? (unsigned)(EBC_WAVE / R) : 1u;
+  g.rows_blocks = (io.ob || io.obs_rotated) ? (unsigned)((h->s.E + g.rows_epw - 1) / g.rows_epw) : 0u;
+  const unsigned long long blocks = 2ull * g.env_blocks + g.orca_blocks + g.rows_blocks;
+  if (blocks >= 2147483648ull) return fail(EBC_ERR_UNSUPPORTED, "ORCA step grid >= 2^31 workgroups");
+  switch (h->orca_gs) {
+    case 2: return launch_orca_step_gs<2>(h, io, (unsigned)blocks, g);
+    case 3: return launch_orca_step_gs<3>(h, io, (unsigned)blocks, g);
+    case 4: return launch_orca_step_gs<4>(h, io, (unsigned)blocks, g);
+    case 5: return launch_orca_step_gs<5>(h, io, (unsigned)blocks, g);
+    case 6: return launch_orca_step_gs<6>(h, io, (unsigned)blocks, g);
+    case 7: return launch_orca_step_gs<7>(h, io, (unsigned)blocks, g);
+    case 8: return launch_orca_step_gs<8>(h, io, (unsigned)blocks, g);
+    case 9: return launch_orca_step_gs<9>(h, io, (unsigned)blocks, g);
+    case 10: return launch_orca_step_gs<10>(h, io, (unsigned)blocks, g);
+    case 12: return launch_orca_step_gs<12>(h, io, (unsigned)blocks, g);
+    case 16: return launch_orca_step_gs<16>(h, io, (unsigned)blocks, g);
+    case 21: return launch_orca_step_gs<21>(h, io, (unsigned)blocks, g);
+    default: return launch_orca_step_gs<32>(h, io, (unsigned)blocks, g);
+  }
 }
 
 int launch_step(Handle *h, const StepIO &io, int policy) {
@@ -402,6 +409,9 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN);
   A_(tile, EN * 2);
   A_(done, n_envs); A_(hact, EN * 2);
+  A_(vel_state, EN); A_(vel_rows, EN); A_(env_done, n_envs); A_(rows_loaded, n_envs); A_(fault, 1);
+  if (rc == EBC_OK && (hipMemset(s.vel_state, 0xFF, EN * 8) != hipSuccess || hipMemset(s.vel_rows, 0xFF, EN * 8) != hipSuccess))
+    rc = EBC_ERR_DEVICE;
 #undef A_
   if (rc == EBC_OK) rc = dev_alloc(h, &s.pool.cursor, n_envs);
   if (rc == EBC_OK) rc = dev_alloc(h, &s.grid_scene, n_envs);
@@ -461,6 +471,9 @@ int ebc_synchronize(void *handle) {
   int rc = check_handle(handle, &h);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
+  unsigned fault = 0;  // a role of the fused ORCA step gave up waiting for another (never expected)
+  HIP_TRY(hipMemcpy(&fault, h->s.fault, sizeof(fault), hipMemcpyDeviceToHost));
+  if (fault) return fail(EBC_ERR_DEVICE, "ORCA step: a mailbox wait timed out; the state is undefined");
   return EBC_OK;
 }
 
@@ -742,3 +755,13 @@ int ebc_timing_read(void *handle, int reset, double *avg_ms, int64_t *launches) 
 }
 
 }  // extern "C"
+
+#ifdef EBC_WAVE_TRACE
+// tools only (libebcsim_trace.so): where the kernels leave their wave timeline, [4][blocks][EBC_TRACE_ROW] u64
+extern "C" int ebc_debug_wave_trace(void *device_buffer, unsigned blocks) {
+  unsigned long long *b = (unsigned long long *)device_buffer;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ebc::g_wave_trace), &b, sizeof(b)) != hipSuccess) return EBC_ERR_DEVICE;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ebc::g_wave_trace_blocks), &blocks, sizeof(blocks)) != hipSuccess) return EBC_ERR_DEVICE;
+  return EBC_OK;
+}
+#endif

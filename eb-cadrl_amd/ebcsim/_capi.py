@@ -6,7 +6,8 @@ import os
 from . import _abi
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libebcsim.so")
+# EBCSIM_LIB: another build of the same library (tools/wave_timeline.py uses the trace build)
+LIB_PATH = os.environ.get("EBCSIM_LIB") or os.path.join(_PKG, "lib", "libebcsim.so")
 
 _lib = None
 

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Per-wave timeline of the step kernels: when each one-wave workgroup started and ended, on the
+device's constant 100 MHz clock, and how many shader cycles it lived.  Needs the trace build:
+
+    make -C eb-cadrl_amd/csrc trace
+    EBCSIM_LIB=eb-cadrl_amd/lib/libebcsim_trace.so python3 tools/wave_timeline.py [workload] [envs]
+
+Prints, per kernel role: first/last start, last end (us from the first start of the launch),
+wave lifetime percentiles, the shader clock the lifetimes imply, and how many waves were resident
+over time.
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "eb-cadrl_amd")):
+    sys.path.insert(0, p)
+
+TAGS = {0: "orca_kernel", 1: "step_kernel", 2: "phase1_kernel", 3: "phase2_kernel"}
+
+
+def main():
+    import numpy as np
+    import torch
+    import bench
+    from ebcsim import _abi, _capi
+    from ebcsim.batched import BatchedEnv
+    workload = sys.argv[1] if len(sys.argv) > 1 else "metric"
+    E = int(sys.argv[2]) if len(sys.argv) > 2 else bench.WORKLOADS[workload][2]
+    L = _capi.lib()
+    L.ebc_debug_wave_trace.restype = C.c_int
+    L.ebc_debug_wave_trace.argtypes = [C.c_void_p, C.c_uint]
+    params, batch = bench.build_batch(workload, E, 0)
+    env = BatchedEnv(params, E, batch.N, batch.S)
+    env.reset(batch)
+    env.use_torch_stream()
+    blocks = 1 << 17
+    buf = torch.zeros((4, blocks, 16), dtype=torch.int64, device="cuda")
+    _capi.check(L.ebc_debug_wave_trace(buf.data_ptr(), blocks))
+    outs = env.alloc_step_outputs(("reward", "done", "info", "obs_rotated"))
+    fl = _abi.FLAG_AUTO_RESET
+    for hp in (_abi.HUMAN_LINEAR, _abi.HUMAN_ORCA):
+        for _ in range(50):
+            env.step_device(outs, human_policy=hp, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+        torch.cuda.synchronize()
+    t = buf.cpu().numpy().astype(np.uint64)
+    launch0 = None
+    for tag in (2, 3, 1):
+        rows = t[tag]
+        idx = np.nonzero(rows[:, 1] != 0)[0]
+        rows = rows[idx]
+        if not len(rows):
+            continue
+        if tag == 2:  # phase 1 carries two roles: blocks [0, env_blocks) service, the rest ORCA
+            env_blocks = -(-E // (64 // batch.N))
+            parts = [("phase1 service", idx < env_blocks), ("phase1 ORCA", idx >= env_blocks)]
+        else:
+            parts = [(TAGS[tag], np.ones(len(idx), bool))]
+        base_all = rows[:, 0].astype(np.int64).min()
+        if tag == 2:
+            launch0 = base_all
+        for name, sel in parts:
+            report(np, name, rows[sel], launch0 if tag == 3 and launch0 is not None else base_all)
+
+
+def report(np, name, rows, base):
+    r0, r1 = rows[:, 0].astype(np.int64), rows[:, 1].astype(np.int64)
+    cyc = (rows[:, 3] - rows[:, 2]).astype(np.int64)
+    us = lambda x: (x - base) / 100.0
+    life = (r1 - r0) / 100.0
+    mhz = np.median(cyc[life > 0] / life[life > 0])
+    print("%s: %d waves; starts %.2f..%.2f us, last end %.2f us" % (
+        name, len(rows), us(r0.min()), us(r0.max()), us(r1.max())))
+    print("   lifetime us p10/p50/p90/max: %.2f %.2f %.2f %.2f; shader clock ~%.0f MHz" % (
+        np.percentile(life, 10), np.percentile(life, 50), np.percentile(life, 90), life.max(), mhz))
+    edges = np.arange(0, us(r1.max()) + 1.0, 1.0)
+    print("   resident waves at t = 0, 1, 2 ... us: " + " ".join(str(int(((us(r0) <= x) & (us(r1) > x)).sum())) for x in edges))
+    print("   started by t:                        " + " ".join(str(int((us(r0) <= x).sum())) for x in edges))
+    if name == "phase2_kernel" and rows[:, 5].any():
+        c0 = rows[:, 2].astype(np.int64)
+        marks = rows[:, 5:10].astype(np.int64) - c0[:, None]
+        seg = np.concatenate([marks[:, :1], np.diff(marks, axis=1), (cyc - marks[:, 4])[:, None]], axis=1)
+        names = ["loads", "move", "frame", "rows", "state stores", "restore+end"]
+        print("   cycles per segment (mean): " + ", ".join("%s %.0f" % (n, seg[:, q].mean()) for q, n in enumerate(names)))
+    if name == "phase1 ORCA" and rows[:, 5].any():
+        c0 = rows[:, 2].astype(np.int64)
+        marks = rows[:, 5:10].astype(np.int64) - c0[:, None]
+        total = cyc
+        names = ["loads", "rank", "lines", "LP2", "LP3", "end"]
+        seg = np.concatenate([marks[:, :1], np.diff(marks, axis=1), (total - marks[:, 4])[:, None]], axis=1)
+        lp1, lp3, lp3it = (rows[:, 11 + q].astype(np.int64) for q in range(3))
+        order = np.argsort(life)
+        for label, pick in (("median waves", order[len(order) // 2 - 50:len(order) // 2 + 50]),
+                            ("slowest 1%", order[-max(1, len(order) // 100):])):
+            print("   %s: cycles per segment " % label + ", ".join(
+                "%s %.0f" % (n, seg[pick, q].mean()) for q, n in enumerate(names)) +
+                "; LP1 calls %.1f, LP3 entered %.2f, LP3 rounds %.1f" % (lp1[pick].mean(), lp3[pick].mean(), lp3it[pick].mean()))
+        print("   LP1 calls per wave: mean %.2f p50 %d p90 %d max %d; waves entering LP3: %.1f%%" % (
+            lp1.mean(), np.percentile(lp1, 50), np.percentile(lp1, 90), lp1.max(), 100.0 * (lp3 > 0).mean()))
+
+
+if __name__ == "__main__":
+    main()
