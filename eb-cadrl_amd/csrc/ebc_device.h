@@ -168,6 +168,16 @@ __device__ __forceinline__ RewardOut reward_compute(const EbcParams &p, double n
 __device__ __forceinline__ float det2(float ax, float ay, float bx, float by) { return ax * by - ay * bx; }
 
 // ORCA.predict's Python-side preferred velocity (simulator/policy/orca.py:136-140)
+// (dx, dy) = goal - position, speed = norm2(dx, dy)
+__device__ __forceinline__ void orca_pref_from(double dx, double dy, double speed, float &prefx, float &prefy) {
+  if (speed > 1) {
+    prefx = (float)(dx / speed);
+    prefy = (float)(dy / speed);
+  } else {
+    prefx = (float)dx;
+    prefy = (float)dy;
+  }
+}
 __device__ __forceinline__ void orca_pref_velocity(double px, double py, double gx, double gy,
                                                    float &prefx, float &prefy) {
   double dx = gx - px, dy = gy - py;

@@ -50,7 +50,7 @@ struct DevState {
   double *spx, *spy, *sradius;
   int *grid_scene;  // [E] pool slot whose occupancy grid env e uses (pool.grid is null when every map is free)
   double *robot;    // [E][9] FullState order
-  double *robot_n;  // [E][9] scratch: next robot state between phase 1 and phase 2
+  double *robot_n;  // [E][9] the fused ORCA step writes the robots' next state here; the host then swaps the two
   double *time;   // [E] global_time
   double *arrival;
   uint8_t *done;  // terminal flag of the last step
@@ -62,6 +62,7 @@ struct DevState {
   unsigned long long *vel_rows;   // [E][N] the same for the ROWS role
   unsigned *env_done;             // [E] ENV -> STATE: 1 + done
   unsigned *rows_loaded;          // [E] ROWS -> STATE: pre-step state has been read (1)
+  unsigned *robot_ready;          // [E] ENV -> ROWS: robot_n[e] holds this step's result (= the launch's epoch; never reset)
   unsigned *fault;                // [1] a poll gave up (protocol broken); ebc_synchronize reports it
   ScenePool pool;  // where auto-reset takes an env's next scene from
   // what rvo2 would hold for the current state (float), one 32-byte record per human slot:
@@ -403,6 +404,47 @@ __device__ __forceinline__ CommitAddr commit_addr(const DevState &s, const StepI
   return a;
 }
 
+// wave-wide: returns once every lane with `need` has found its word non-empty (or gave up)
+template <typename W>
+__device__ __forceinline__ W mailbox_wait(W *box, bool need, W empty, unsigned *fault) {
+  W v = empty;
+  bool waiting = need;
+  for (unsigned spins = 0;; ++spins) {
+    if (waiting) {
+      v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      waiting = v == empty;
+    }
+    if (!__any(waiting)) break;
+    if (spins > EBC_SPIN_LIMIT) {
+      if (waiting) atomicOr(fault, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return v;
+}
+// the same for a box that holds the launch's epoch when ready (several readers, never emptied)
+__device__ __forceinline__ void mailbox_wait_epoch(unsigned *box, bool need, unsigned epoch, unsigned *fault) {
+  bool waiting = need;
+  for (unsigned spins = 0;; ++spins) {
+    if (waiting) waiting = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
+    if (!__any(waiting)) break;
+    if (spins > EBC_SPIN_LIMIT) {
+      if (waiting) atomicOr(fault, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+template <typename W>
+__device__ __forceinline__ void mailbox_put(W *box, W v) {
+  __hip_atomic_store(box, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void unpack_velocity(unsigned long long v, double &ax, double &ay) {
+  ax = (double)__uint_as_float((unsigned)v);  // getAgentVelocity -> Python float
+  ay = (double)__uint_as_float((unsigned)(v >> 32));
+}
+
 // The robot's action for this step (its policy, or the caller's) — env.py:388-392.
 __device__ __forceinline__ void robot_action(const StepIO &io, size_t ee, const double *rb, double &a0, double &a1) {
   if (io.robot_policy == EBC_ROBOT_LINEAR) {
@@ -431,9 +473,12 @@ __device__ __forceinline__ void robot_advance(const EbcParams &p, double *rb, do
 }
 
 // Leader lanes return the step's done flag and leave the robot's NEXT state in rb.
+// `epoch` != 0 (fused ORCA step): the leader publishes the robot's next state in s.robot_n as soon
+// as the action is known — the ROWS role builds the observation frame from it long before the
+// collision / reward work below is done.
 __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s, const StepIO &io,
                                            const LaneMap &m, const HumanRegs &h, double rb[9],
-                                           double gtime, int lane) {
+                                           double gtime, int lane, unsigned epoch = 0) {
   __shared__ double sh_d[EBC_WAVE];
   __shared__ double sh_ract[EBC_WAVE][2];
   __shared__ uint8_t sh_type[EBC_WAVE];
@@ -450,6 +495,18 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
     }
     sh_ract[m.el][0] = a0;
     sh_ract[m.el][1] = a1;
+    if (epoch) {
+      double rn[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) rn[c] = rb[c];
+      robot_advance(p, rn, a0, a1);
+      // Device-scope stores go through to memory; the flag is stored (below, after the distance
+      // work) once they have been acknowledged.  (An agent-scope release FENCE would do, but on this
+      // part it writes back the whole L2 of the XCD: it doubled the step time.)
+      double *o = s.robot_n + m.ee * 9;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) __hip_atomic_store(o + c, rn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   wave_sync();
   const double a0 = sh_ract[m.env_ok ? m.el : 0][0], a1 = sh_ract[m.env_ok ? m.el : 0][1];
@@ -464,6 +521,10 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
   sh_d[lane] = m.active ? closest_dist(h.px, h.py, h.vx, h.vy, h.rad, rb[0], rb[1], rb[4], rvx, rvy, dt) : 0.0;
   sh_type[lane] = (uint8_t)h.type;
   wave_sync();
+  if (epoch) {  // the stores of robot_n went out a distance computation ago: this wait is short
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (m.leader) mailbox_put(s.robot_ready + m.ee, epoch);
+  }
   if (!m.leader) return 0;
   // ordered per-type reduction with break at the first hit (env.py:303-313)
   double dm0 = INFINITY, dm1 = INFINITY, dm2 = INFINITY;
@@ -513,13 +574,12 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
 
 // The state the next step will see: the moved humans and their float tile entries, or — after a
 // terminal step under auto-reset — the env's next scene.
-template <bool WITH_ROBOT = true>
 __device__ __forceinline__ void commit_state_tail(const EbcParams &p, const DevState &s, const LaneMap &m,
                                                   const HumanRegs &h, const CommitPre &pre,
-                                                  const CommitAddr &A, bool restore, bool restore_later) {
+                                                  const CommitAddr &A, bool restore) {
   const int N = s.N, S = s.S;
   // the humans: the moved state ...
-  if (m.active && !restore && !restore_later) {
+  if (m.active && !restore) {
     *A.px = h.px;
     *A.py = h.py;
     *A.vx = h.vx;
@@ -530,7 +590,6 @@ __device__ __forceinline__ void commit_state_tail(const EbcParams &p, const DevS
     A.tile[0] = make_float4((float)h.px, (float)h.py, (float)h.vx, (float)h.vy);
     A.tile[1] = make_float4((float)(h.rad + 0.01 + p.orca_safety_space), (float)h.vpref, prefx, prefy);
   }
-  EBC_MARK(4);
   // ... or, after a terminal step under auto-reset, the env's next scene from the pool: every
   // per-scene field (ragged human count, goals, radii, static rows, map), time 0.  Rare path: its
   // loads sit behind the step's stores on purpose.
@@ -566,13 +625,8 @@ __device__ __forceinline__ void commit_state_tail(const EbcParams &p, const DevS
       s.n_humans[m.ee] = n_new;
       if (S) s.n_static[m.ee] = pre.n_static;
       s.grid_scene[m.ee] = pre.cursor;
-      if (WITH_ROBOT) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) A.robot[q] = pre.robot[q];
-      } else {  // the caller did not hold the restart robot in registers: copy it now
-        const double *src = P.robot + (size_t)pre.cursor * 9;
-        for (int q = 0; q < 9; ++q) A.robot[q] = src[q];
-      }
+      for (int q = 0; q < 9; ++q) A.robot[q] = pre.robot[q];
       *A.time = 0.0;
       if (P.P > 0) {  // walk the custom pool; without one the env keeps restarting from its own slot
         int nxt = pre.cursor - s.E + P.stride;
@@ -600,10 +654,8 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
     ax = 0;
     ay = 0;
   }
-  EBC_MARK(1);
   const RotFrame f = rot_frame(rbn, p.rotate_unicycle);
   pin_pool(pre);  // first store of the commit below
-  EBC_MARK(2);
   if (m.leader && !restore) {  // the robot: the moved state (the restart scene: restore path)
 #pragma unroll
     for (int c = 0; c < 9; ++c) A.robot[c] = rbn[c];
@@ -653,8 +705,7 @@ __device__ __forceinline__ void service_commit(const EbcParams &p, const DevStat
       }
     }
   }
-  EBC_MARK(3);
-  commit_state_tail(p, s, m, h, pre, A, restore, false);
+  commit_state_tail(p, s, m, h, pre, A, restore);
 }
 
 __device__ __forceinline__ void load_robot(const DevState &s, const LaneMap &m, double rb[9]) {
@@ -731,43 +782,18 @@ __global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState
 struct StepGrid {
   unsigned env_blocks, orca_blocks, rows_blocks;  // then env_blocks STATE blocks
   unsigned rows_epw;                               // envs per ROWS wave (1 when N + S > 64)
+  unsigned epoch;                                  // launch counter, never 0
 };
 
-// wave-wide: returns once every lane with `need` has found its word non-empty (or gave up)
-template <typename W>
-__device__ __forceinline__ W mailbox_wait(W *box, bool need, W empty, unsigned *fault) {
-  W v = empty;
-  bool waiting = need;
-  for (unsigned spins = 0;; ++spins) {
-    if (waiting) {
-      v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      waiting = v == empty;
-    }
-    if (!__any(waiting)) break;
-    if (spins > EBC_SPIN_LIMIT) {
-      if (waiting) atomicOr(fault, 1u);
-      break;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  return v;
-}
-template <typename W>
-__device__ __forceinline__ void mailbox_put(W *box, W v) {
-  __hip_atomic_store(box, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void unpack_velocity(unsigned long long v, double &ax, double &ay) {
-  ax = (double)__uint_as_float((unsigned)v);  // getAgentVelocity -> Python float
-  ay = (double)__uint_as_float((unsigned)(v >> 32));
-}
-
+#define EBC_RBN_ENVS 16  // envs per STATE wave whose restart robot is parked in LDS (more: late loads)
 struct RoleLds {
   ArgBlock args;
+  double restart_robot[EBC_RBN_ENVS][9];  // STATE
 };
 
 // ---- ENV
 __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in,
-                                         RoleLds &L, int block, int lane) {
+                                         RoleLds &L, int block, unsigned epoch, int lane) {
   stage_args(&L.args.p, p_in, lane);
   stage_args(&L.args.s, s_in, lane);
   stage_args(&L.args.io, io_in, lane);
@@ -785,7 +811,7 @@ __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &
   pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type); pin(gtime); pin(done_box);
 #pragma unroll
   for (int q = 0; q < 9; ++q) pin(rb[q]);
-  const int done = service_env(p, s, io, m, h, rb, gtime, lane);
+  const int done = service_env(p, s, io, m, h, rb, gtime, lane, epoch);
   if (m.leader) mailbox_put(done_box, 1u + (unsigned)done);
 }
 
@@ -817,7 +843,7 @@ __device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s,
 // ns + i, static slot j >= ns -> N + j.
 template <int T>
 __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in,
-                                          RoleLds &L, unsigned block, unsigned epw, int lane) {
+                                          RoleLds &L, unsigned block, unsigned epw, unsigned epoch, int lane) {
   stage_args(&L.args.p, p_in, lane);
   stage_args(&L.args.s, s_in, lane);
   stage_args(&L.args.io, io_in, lane);
@@ -832,18 +858,7 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
   const bool env_ok = el < (int)epw && e < s.E;
   const size_t ee = env_ok ? (size_t)e : 0;
   const int stride = R <= EBC_WAVE ? R : EBC_WAVE;  // one pass unless an env has more rows than lanes
-  // the robot's next state, from its pre-step state and this step's action.  Done before the row
-  // loads are issued: nothing here is urgent (the velocities arrive microseconds later) and the
-  // policy's trigonometry would otherwise hold its temporaries beside the row data.
-  double rb[9];
-#pragma unroll
-  for (int c = 0; c < 9; ++c) rb[c] = env_ok ? s.robot[ee * 9 + c] : 0.0;
-  {
-    double a0 = 0, a1 = 0;
-    if (env_ok) robot_action(io, ee, rb, a0, a1);
-    robot_advance(p, rb, a0, a1);
-  }
-  const RotFrame f = rot_frame(rb, p.rotate_unicycle);
+  RotFrame f = {};
   int n = env_ok ? s.n_humans[ee] : 0;
   int ns = (env_ok && S) ? s.n_static[ee] : 0;
   for (int slot = first; slot < R; slot += stride) {
@@ -858,7 +873,18 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
     }
     unsigned long long *vbox = s.vel_rows + k;
     pin(opx); pin(opy); pin(orad); pin(otype); pin(vbox); pin(n); pin(ns);
-    // every pre-step value this env's rows need is in registers: STATE may overwrite the state
+    if (slot == first) {
+      // the robot's next state: the ENV role publishes it early in its run (service_env)
+      mailbox_wait_epoch(s.robot_ready + ee, env_ok, epoch, s.fault);
+      double rb[9];  // device-scope loads, issued after the flag was seen: they do not come from a stale cache line
+#pragma unroll
+      for (int c = 0; c < 9; ++c)
+        rb[c] = env_ok ? __hip_atomic_load(s.robot_n + ee * 9 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      f = rot_frame(rb, p.rotate_unicycle);
+      pin(f.px); pin(f.py); pin(f.dg);
+    }
+    // every value of this step's state that this env's rows need is in registers: STATE may
+    // overwrite the humans, and on a restart robot_n[e]
     if (env_ok && slot + stride >= R && first == 0) mailbox_put(s.rows_loaded + ee, 1u);
     const bool valid = human ? slot < n : slot - N < ns;
     const int row = human ? (valid ? slot : ns + slot) : (valid ? n + slot - N : slot);
@@ -906,16 +932,6 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   const StepIO &io = L.args.io;
   const int epb = EBC_WAVE / s.N;
   const LaneMap m = lane_map(s, block * epb, epb, lane);
-  // the robot's next state first (see rows_role), then the humans
-  double rb[9];
-  load_robot(s, m, rb);
-  if (m.leader) {
-    double a0, a1;
-    robot_action(io, m.ee, rb, a0, a1);
-    robot_advance(p, rb, a0, a1);
-  }
-#pragma unroll
-  for (int q = 0; q < 9; ++q) pin(rb[q]);
   double gtime = m.env_ok ? s.time[m.ee] : 0.0;
   HumanRegs h = load_human(s, m);
   StepIO io_state = io;  // no observation rows here: CommitPre's static-row preloads stay empty
@@ -923,13 +939,34 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   io_state.obs_rotated = nullptr;
   unsigned long long *vbox = s.vel_state + m.k;
   unsigned *done_box = s.env_done + m.ee, *loaded_box = s.rows_loaded + m.ee;
+  // The restart scene (cursor, then the scene: two round trips) while there is nothing else to
+  // do, and what can be derived from it ahead of time: its preferred velocity (a double sqrt and
+  // two divisions) and, parked in LDS, the restart robot.
+  CommitPre pre = preload_commit<false>(s, io_state, m);
+  float rprefx = 0, rprefy = 0;
+  const bool parked = m.el < EBC_RBN_ENVS;
+  if (io.auto_reset && m.env_ok) {
+    orca_pref_velocity(pre.px, pre.py, pre.gx, pre.gy, rprefx, rprefy);
+    if (m.leader && parked) {
+      const double *src = s.pool.robot + (size_t)pre.cursor * 9;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) L.restart_robot[m.el][q] = src[q];
+    }
+  }
+  const float tile_rad = (float)(h.rad + 0.01 + p.orca_safety_space), tile_max = (float)h.vpref;  // orca.py:116-126
   pin(vbox); pin(done_box); pin(loaded_box);
-  pin(h.px); pin(h.py); pin(h.gx); pin(h.gy); pin(h.rad); pin(h.vpref); pin(h.arrival); pin(gtime);
+  pin(h.px); pin(h.py); pin(h.gx); pin(h.gy); pin(h.rad); pin(h.arrival); pin(gtime);
+  pin(pre.cursor); pin(pre.px); pin(pre.py); pin(pre.vx); pin(pre.vy); pin(pre.gx); pin(pre.gy); pin(pre.rad);
+  pin(pre.vpref); pin(pre.spx); pin(pre.spy); pin(pre.srad); pin(pre.type); pin(pre.n_humans); pin(pre.n_static);
+  pin(rprefx); pin(rprefy);
+  wave_sync();  // restart_robot
+  EBC_MARK(0);
   // wait for this wave's humans (every ORCA group of these envs has then read the tile and the
   // robot), for the envs' robot-side result, and for the ROWS waves to have read the old state
   const unsigned long long v = mailbox_wait(vbox, m.env_ok, (unsigned long long)EBC_SLOT_EMPTY, s.fault);
   const unsigned d = mailbox_wait(done_box, m.env_ok, 0u, s.fault);
   if (wait_rows) mailbox_wait(loaded_box, m.env_ok, 0u, s.fault);
+  EBC_MARK(1);
   if (!m.env_ok) return;
   mailbox_put(vbox, (unsigned long long)EBC_SLOT_EMPTY);
   if (m.leader) {
@@ -938,38 +975,91 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   }
   const bool restore = io.auto_reset && d == 2u;
   const double tnew = gtime + p.time_step;
-  const CommitAddr A = commit_addr<false>(s, io_state, m);
+  const int N = s.N, S = s.S;
+  float4 *tile = s.tile + 2 * m.k;
   double ax = 0, ay = 0;
-  if (m.active) {  // Agent.step (agent.py:202-211), first arrival (env.py:365-378)
-    unpack_velocity(v, ax, ay);
-    h.px = h.px + ax * p.time_step;
-    h.py = h.py + ay * p.time_step;
-    h.vx = ax;
-    h.vy = ay;
-    if (h.arrival == 0 && norm2(h.px - h.gx, h.py - h.gy) < h.rad) h.arrival = tnew;
+  if (m.active) unpack_velocity(v, ax, ay);
+  if (io.human_action) {
+    io.human_action[m.k * 2] = ax;
+    io.human_action[m.k * 2 + 1] = ay;
   }
-  if (m.leader && !restore) {  // the robot: the moved state (the restart scene: restore path)
+  if (!restore) {
+    if (m.active) {  // Agent.step (agent.py:202-211), first arrival (env.py:365-378)
+      h.px = h.px + ax * p.time_step;
+      h.py = h.py + ay * p.time_step;
+      // one norm serves the arrival test and the preferred velocity of the float tile
+      // (orca.py:136-140): |position - goal| == |goal - position| bit for bit
+      const double dx = h.gx - h.px, dy = h.gy - h.py;
+      const double dist = norm2(dx, dy);
+      if (h.arrival == 0 && dist < h.rad) h.arrival = tnew;
+      float prefx, prefy;
+      orca_pref_from(dx, dy, dist, prefx, prefy);
+      s.px[m.k] = h.px;
+      s.py[m.k] = h.py;
+      s.vx[m.k] = ax;
+      s.vy[m.k] = ay;
+      s.arrival[m.k] = h.arrival;
+      tile[0] = make_float4((float)h.px, (float)h.py, (float)ax, (float)ay);
+      tile[1] = make_float4(tile_rad, tile_max, prefx, prefy);
+    }
+    if (m.leader) s.time[m.ee] = tnew;  // the robot's next state is in robot_n already (ENV)
+  } else {
+    // a terminal env under auto-reset takes its next scene: every per-scene field (ragged human
+    // count, goals, radii, static rows, map), time 0
+    const ScenePool &P = s.pool;
+    const bool live = m.i < pre.n_humans;
+    s.px[m.k] = live ? pre.px : 0.0;
+    s.py[m.k] = live ? pre.py : 0.0;
+    s.vx[m.k] = live ? pre.vx : 0.0;
+    s.vy[m.k] = live ? pre.vy : 0.0;
+    s.arrival[m.k] = 0.0;
+    s.gx[m.k] = live ? pre.gx : 0.0;
+    s.gy[m.k] = live ? pre.gy : 0.0;
+    s.radius[m.k] = live ? pre.rad : 0.0;
+    s.v_pref[m.k] = live ? pre.vpref : 0.0;
+    s.type[m.k] = live ? (uint8_t)pre.type : (uint8_t)0;
+    if (live) {
+      tile[0] = make_float4((float)pre.px, (float)pre.py, (float)pre.vx, (float)pre.vy);
+      tile[1] = make_float4((float)(pre.rad + 0.01 + p.orca_safety_space), (float)pre.vpref, rprefx, rprefy);
+    } else {
+      tile[0] = make_float4(0, 0, 0, 0);
+      tile[1] = make_float4(0, 0, 0, 0);
+    }
+    if (m.i < S) {
+      s.spx[m.ee * S + m.i] = pre.spx;
+      s.spy[m.ee * S + m.i] = pre.spy;
+      s.sradius[m.ee * S + m.i] = pre.srad;
+    }
+    for (int q = m.i + N; q < S; q += N) {  // more static rows than humans: late loads (rare)
+      const size_t c = (size_t)pre.cursor * S + q;
+      s.spx[m.ee * S + q] = P.spx[c];
+      s.spy[m.ee * S + q] = P.spy[c];
+      s.sradius[m.ee * S + q] = P.sradius[c];
+    }
+    if (m.leader) {
+      s.n_humans[m.ee] = pre.n_humans;
+      if (S) s.n_static[m.ee] = pre.n_static;
+      s.grid_scene[m.ee] = pre.cursor;
+      double *rdst = s.robot_n + m.ee * 9;  // where the next step reads the robot: overwrites ENV's result
+      if (parked) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) A.robot[c] = rb[c];
-    *A.time = tnew;
+        for (int q = 0; q < 9; ++q) rdst[q] = L.restart_robot[m.el][q];
+      } else {
+        const double *src = P.robot + (size_t)pre.cursor * 9;
+        for (int q = 0; q < 9; ++q) rdst[q] = src[q];
+      }
+      s.time[m.ee] = 0.0;
+      if (P.P > 0) {  // walk the custom pool; without one the env keeps restarting from its own slot
+        int nxt = pre.cursor - s.E + P.stride;
+        P.cursor[m.ee] = s.E + (nxt >= P.P ? nxt % P.P : nxt);
+      }
+    }
   }
-  if (A.human_action) {
-    A.human_action[0] = ax;
-    A.human_action[1] = ay;
-  }
-  CommitPre none = {};
-  commit_state_tail(p, s, m, h, none, A, false, restore);
-  // A terminal env under auto-reset takes its next scene now.  Its loads start here (cursor, then
-  // the scene: two round trips): such waves finish later than the rest, but a launch ends with
-  // its slowest ORCA waves, long after most STATE waves, so the restart is seldom what is last.
-  if (__any(restore)) {
-    const CommitPre pre = preload_commit<false>(s, io_state, m);
-    if (restore) commit_state_tail<false>(p, s, m, h, pre, A, true, false);
-  }
+  EBC_MARK(2);
 }
 
 #ifndef EBC_STEP_WAVES
-#define EBC_STEP_WAVES 7
+#define EBC_STEP_WAVES 6
 #endif
 template <int GS, int T>
 __global__ __launch_bounds__(EBC_WAVE, EBC_STEP_WAVES) void orca_step_kernel(EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
@@ -984,7 +1074,7 @@ __global__ __launch_bounds__(EBC_WAVE, EBC_STEP_WAVES) void orca_step_kernel(Ebc
 #endif
   if (b < g.env_blocks) {
     __builtin_amdgcn_s_setprio(3);  // the long dependent chain of the launch
-    if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, lane);
+    if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, g.epoch, lane);
     return;
   }
   b -= g.env_blocks;
@@ -994,7 +1084,7 @@ __global__ __launch_bounds__(EBC_WAVE, EBC_STEP_WAVES) void orca_step_kernel(Ebc
   }
   b -= g.orca_blocks;
   if (b < g.rows_blocks) {
-    if (EBC_ROLE_MASK & 4) rows_role<T>(p_in, s_in, io_in, L, b, g.rows_epw, lane);
+    if (EBC_ROLE_MASK & 4) rows_role<T>(p_in, s_in, io_in, L, b, g.rows_epw, g.epoch, lane);
     return;
   }
   b -= g.rows_blocks;

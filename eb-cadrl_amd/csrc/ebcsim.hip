@@ -44,6 +44,7 @@ struct Handle {
   hipStream_t stream = nullptr;
   bool has_reset = false;
   int orca_gs = 16;  // lanes per human of the ORCA waves
+  unsigned epoch = 0;  // fused ORCA steps launched so far (StepGrid::epoch)
   std::vector<void *> pool_allocs;   // pool arrays (re-allocated by ebc_set_scene_pool)
   uint64_t *pool_grid_alloc = nullptr;
   // staging for host-location calls
@@ -170,6 +171,8 @@ int launch_orca_step_gs(Handle *h, const StepIO &io, unsigned blocks, const ebc:
   return EBC_OK;
 }
 
+int launch_orca_step_sized(Handle *h, const StepIO &io, unsigned blocks, const ebc::StepGrid &g);
+
 int launch_orca_step(Handle *h, const StepIO &io) {
   const int epb = EBC_WAVE / h->s.N;
   const int R = h->s.N + h->s.S;
@@ -180,20 +183,29 @@ int launch_orca_step(Handle *h, const StepIO &io) {
   g.rows_blocks = (io.ob || io.obs_rotated) ? (unsigned)((h->s.E + g.rows_epw - 1) / g.rows_epw) : 0u;
   const unsigned long long blocks = 2ull * g.env_blocks + g.orca_blocks + g.rows_blocks;
   if (blocks >= 2147483648ull) return fail(EBC_ERR_UNSUPPORTED, "ORCA step grid >= 2^31 workgroups");
+  if (++h->epoch == 0) h->epoch = 1;  // robot_ready boxes hold the epoch of the launch that filled them
+  g.epoch = h->epoch;
+  const int rc = launch_orca_step_sized(h, io, blocks, g);
+  // the launch leaves the robots' next state in robot_n: that is the current state from here on
+  if (rc == EBC_OK) std::swap(h->s.robot, h->s.robot_n);
+  return rc;
+}
+
+int launch_orca_step_sized(Handle *h, const StepIO &io, unsigned blocks, const ebc::StepGrid &g) {
   switch (h->orca_gs) {
-    case 2: return launch_orca_step_gs<2>(h, io, (unsigned)blocks, g);
-    case 3: return launch_orca_step_gs<3>(h, io, (unsigned)blocks, g);
-    case 4: return launch_orca_step_gs<4>(h, io, (unsigned)blocks, g);
-    case 5: return launch_orca_step_gs<5>(h, io, (unsigned)blocks, g);
-    case 6: return launch_orca_step_gs<6>(h, io, (unsigned)blocks, g);
-    case 7: return launch_orca_step_gs<7>(h, io, (unsigned)blocks, g);
-    case 8: return launch_orca_step_gs<8>(h, io, (unsigned)blocks, g);
-    case 9: return launch_orca_step_gs<9>(h, io, (unsigned)blocks, g);
-    case 10: return launch_orca_step_gs<10>(h, io, (unsigned)blocks, g);
-    case 12: return launch_orca_step_gs<12>(h, io, (unsigned)blocks, g);
-    case 16: return launch_orca_step_gs<16>(h, io, (unsigned)blocks, g);
-    case 21: return launch_orca_step_gs<21>(h, io, (unsigned)blocks, g);
-    default: return launch_orca_step_gs<32>(h, io, (unsigned)blocks, g);
+    case 2: return launch_orca_step_gs<2>(h, io, blocks, g);
+    case 3: return launch_orca_step_gs<3>(h, io, blocks, g);
+    case 4: return launch_orca_step_gs<4>(h, io, blocks, g);
+    case 5: return launch_orca_step_gs<5>(h, io, blocks, g);
+    case 6: return launch_orca_step_gs<6>(h, io, blocks, g);
+    case 7: return launch_orca_step_gs<7>(h, io, blocks, g);
+    case 8: return launch_orca_step_gs<8>(h, io, blocks, g);
+    case 9: return launch_orca_step_gs<9>(h, io, blocks, g);
+    case 10: return launch_orca_step_gs<10>(h, io, blocks, g);
+    case 12: return launch_orca_step_gs<12>(h, io, blocks, g);
+    case 16: return launch_orca_step_gs<16>(h, io, blocks, g);
+    case 21: return launch_orca_step_gs<21>(h, io, blocks, g);
+    default: return launch_orca_step_gs<32>(h, io, blocks, g);
   }
 }
 
@@ -409,7 +421,7 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN);
   A_(tile, EN * 2);
   A_(done, n_envs); A_(hact, EN * 2);
-  A_(vel_state, EN); A_(vel_rows, EN); A_(env_done, n_envs); A_(rows_loaded, n_envs); A_(fault, 1);
+  A_(vel_state, EN); A_(vel_rows, EN); A_(env_done, n_envs); A_(rows_loaded, n_envs); A_(robot_ready, n_envs); A_(fault, 1);
   if (rc == EBC_OK && (hipMemset(s.vel_state, 0xFF, EN * 8) != hipSuccess || hipMemset(s.vel_rows, 0xFF, EN * 8) != hipSuccess))
     rc = EBC_ERR_DEVICE;
 #undef A_

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "eb-cadrl_amd")):
     sys.path.insert(0, p)
 
-TAGS = {0: "orca_kernel", 1: "step_kernel", 2: "phase1_kernel", 3: "phase2_kernel"}
+TAGS = {0: "orca_kernel", 1: "step_kernel", 2: "orca_step_kernel", 3: "(unused)"}
 
 
 def main():
@@ -52,16 +52,25 @@ def main():
         rows = rows[idx]
         if not len(rows):
             continue
-        if tag == 2:  # phase 1 carries two roles: blocks [0, env_blocks) service, the rest ORCA
+        if tag == 2:  # orca_step_kernel: blocks in role order ENV, ORCA, ROWS, STATE
             env_blocks = -(-E // (64 // batch.N))
-            parts = [("phase1 service", idx < env_blocks), ("phase1 ORCA", idx >= env_blocks)]
+            others = batch.N - 1 + (1 if params.robot_visible else 0)
+            gs = next(g for g in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32) if g >= others)
+            orca_blocks = -(-E * batch.N // (64 // gs))
+            R = batch.N + batch.S
+            epw = 64 // R if R <= 64 else 1
+            rows_blocks = -(-E // epw)
+            b1, b2, b3 = env_blocks, env_blocks + orca_blocks, env_blocks + orca_blocks + rows_blocks
+            parts = [("ENV", idx < b1), ("phase1 ORCA", (idx >= b1) & (idx < b2)),
+                     ("ROWS", (idx >= b2) & (idx < b3)), ("STATE", idx >= b3)]
         else:
             parts = [(TAGS[tag], np.ones(len(idx), bool))]
         base_all = rows[:, 0].astype(np.int64).min()
         if tag == 2:
             launch0 = base_all
         for name, sel in parts:
-            report(np, name, rows[sel], launch0 if tag == 3 and launch0 is not None else base_all)
+            if sel.any():
+                report(np, name, rows[sel], launch0 if tag == 3 and launch0 is not None else base_all)
 
 
 def report(np, name, rows, base):
@@ -77,12 +86,12 @@ def report(np, name, rows, base):
     edges = np.arange(0, us(r1.max()) + 1.0, 1.0)
     print("   resident waves at t = 0, 1, 2 ... us: " + " ".join(str(int(((us(r0) <= x) & (us(r1) > x)).sum())) for x in edges))
     print("   started by t:                        " + " ".join(str(int((us(r0) <= x).sum())) for x in edges))
-    if name == "phase2_kernel" and rows[:, 5].any():
+    if name == "STATE" and rows[:, 5].any():
         c0 = rows[:, 2].astype(np.int64)
-        marks = rows[:, 5:10].astype(np.int64) - c0[:, None]
-        seg = np.concatenate([marks[:, :1], np.diff(marks, axis=1), (cyc - marks[:, 4])[:, None]], axis=1)
-        names = ["loads", "move", "frame", "rows", "state stores", "restore+end"]
-        print("   cycles per segment (mean): " + ", ".join("%s %.0f" % (n, seg[:, q].mean()) for q, n in enumerate(names)))
+        mk = rows[:, 5:9].astype(np.int64)
+        segs = [mk[:, 0] - c0, mk[:, 1] - mk[:, 0], mk[:, 2] - mk[:, 1], mk[:, 3] - mk[:, 2]]
+        names = ["start->loads ready", "waiting", "wait->moved state stored", "restart scene stored"]
+        print("   cycles mean / p90: " + ", ".join("%s %.0f / %.0f" % (n, v.mean(), np.percentile(v, 90)) for n, v in zip(names, segs)))
     if name == "phase1 ORCA" and rows[:, 5].any():
         c0 = rows[:, 2].astype(np.int64)
         marks = rows[:, 5:10].astype(np.int64) - c0[:, None]
