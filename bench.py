@@ -183,13 +183,13 @@ def main():
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: %d envs/GPU x %d humans + %d static rows, ORCA + kinematics + "
-                                   "collisions + reward + rotated obs (T=%d), one ebc_step (two HIP launches) per step, "
+                                   "collisions + reward + rotated obs (T=%d), one ebc_step (one HIP launch) per step, "
                                    "auto-reset%s" % (args.workload, E, batch.N, batch.S, env.T,
                                                    "" if hp == _abi.HUMAN_ORCA else " [DIAGNOSTIC: linear humans]"),
                        "envs_per_gpu": E, "humans": int(batch.N), "parallelism": "env-slice x%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "phase1_kernel + phase2_kernel (the two launches of one step)",
+                         "kernel": "orca_step_kernel (the one launch of a step)",
                          "kernel_ms": kernel_ms,
                          "stream_ms_per_step": stream_ms / args.steps,
                          "algorithmic_bytes_per_launch": bytes_launch},

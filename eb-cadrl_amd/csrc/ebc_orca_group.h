@@ -131,12 +131,14 @@ __device__ __forceinline__ void lp1_segments(const Line4 &own, int j, const floa
   wave_sync();
 }
 
-// linearProgram2 over n lines (own = line j; lines and their segments also in LDS).  Returns
-// lineFail (n = ok).  Equivalent to the serial scan: the result only changes at a violated line,
-// so the next line the serial loop acts on is the first violated one at or after `start`.
+// linearProgram2 over n lines (own = line j; lines also in LDS).  Returns lineFail (n = ok).
+// Equivalent to the serial scan: the result only changes at a violated line, so the next line the
+// serial loop acts on is the first violated one at or after `start`.  The segments are worked out
+// when the first violated line turns up: most humans walk at their preferred velocity with no
+// line violated, and a wave none of whose humans needs them skips that work altogether.
 template <int GS>
 __device__ __forceinline__ int lp2_group(const Line4 &own, int j, const float4 *lines_lds,
-                                         const float4 *segs_lds, int n, float radius, float ovx,
+                                         float4 *segs_lds, int n, float radius, float ovx,
                                          float ovy, bool dirOpt, int group, float &rx, float &ry) {
   if (dirOpt) {
     rx = ovx * radius;
@@ -150,10 +152,15 @@ __device__ __forceinline__ int lp2_group(const Line4 &own, int j, const float4 *
     ry = ovy;
   }
   int start = 0;
+  bool have_segments = false;
   while (true) {
     const bool viol = j >= start && j < n && det2(own.dx, own.dy, own.px - rx, own.py - ry) > 0.0f;
     const unsigned m = group_ballot<GS>(viol, group);
     if (m == 0) return n;
+    if (!have_segments) {
+      lp1_segments<GS>(own, j, lines_lds, segs_lds, n, radius);
+      have_segments = true;
+    }
     const int k = __ffs(m) - 1;
     EBC_COUNT(0);
     const float4 lk = lines_lds[k];
@@ -273,8 +280,6 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
     own = Line4{q.x, q.y, q.z, q.w};
   }
   EBC_MARK(2);
-  lp1_segments<GS>(own, j, lines_lds, segs_lds, nn, maxSpeed);
-
   float rx, ry;
   const int lineFail = lp2_group<GS>(own, j, lines_lds, segs_lds, nn, maxSpeed, prefx, prefy, false, group, rx, ry);
   EBC_MARK(3);
@@ -322,7 +327,6 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
         const float4 q = proj_lds[j];
         pown = Line4{q.x, q.y, q.z, q.w};
       }
-      lp1_segments<GS>(pown, j, proj_lds, segs_lds, np, maxSpeed);
       float tx = rx, ty = ry;
       if (lp2_group<GS>(pown, j, proj_lds, segs_lds, np, maxSpeed, -li.dy, li.dx, true, group, tx, ty) >= np) {
         rx = tx;

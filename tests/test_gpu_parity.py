@@ -366,6 +366,51 @@ def test_maximum_actions_and_rows():
                   o.step(robot_action=space[:E], human_policy=_abi.HUMAN_ORCA), "max sizes")
 
 
+def test_orca_step_roles_without_rows_and_wide_envs():
+    """The one-launch ORCA step (ENV / ORCA / ROWS / STATE roles meeting through mailbox words):
+    without observation outputs the ROWS role is absent and its mailboxes must stay empty for a
+    later step that has rows; an env with more rows than a wave has lanes takes several passes."""
+    import torch
+    from oracle import oracle
+    params = params_of(load("traj_n10_walls_t17_orcasub"))
+    rs = np.random.RandomState(77)
+    E, N, S = 50, 7, 3
+    b = _synthetic_batch(rs, E, N, S)
+    g = _env(params, E, N, S)
+    o = oracle.OracleEnv(params, E, N, S)
+    g.reset(b)
+    o.reset(b)
+    g.use_torch_stream()
+    slim = g.alloc_step_outputs(("reward", "done"))
+    full = g.alloc_step_outputs(("reward", "done", "info", "ob", "obs_rotated", "human_action"))
+    fl = _abi.FLAG_AUTO_RESET
+    for t in range(24):
+        outs = slim if (t // 4) % 2 == 0 else full  # 4 steps without rows, 4 with, ...
+        g.step_device(outs, human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+        ref = o.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+        g.synchronize()  # also reports a mailbox timeout
+        np.testing.assert_array_equal(outs["done"].cpu().numpy(), ref["done"], err_msg="step %d" % t)
+        np.testing.assert_allclose(outs["reward"].cpu().numpy(), ref["reward"], atol=1e-9, rtol=0)
+        if outs is full:
+            np.testing.assert_allclose(outs["ob"].cpu().numpy(), ref["ob"], atol=1e-9, rtol=0, err_msg="step %d" % t)
+            np.testing.assert_allclose(outs["human_action"].cpu().numpy(), ref["human_action"], atol=1e-9, rtol=0)
+            np.testing.assert_allclose(outs["obs_rotated"].cpu().numpy(), ref["obs_rotated"], atol=1e-5, rtol=1e-5)
+    sg, so = g.get_state(), o.get_state()
+    for k in sg:
+        np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
+    # 33 + 95 = 128 rows per env: two passes of the ROWS lanes, one env per wave
+    E, N, S = 6, 33, 95
+    b = _synthetic_batch(rs, E, N, S, n_lo=28, walls=False)
+    g = _env(params, E, N, S)
+    o = oracle.OracleEnv(params, E, N, S)
+    g.reset(b)
+    o.reset(b)
+    act = rs.uniform(-0.7, 0.7, size=(E, 2))
+    for t in range(4):
+        _compare_step(g.step(robot_action=act, human_policy=_abi.HUMAN_ORCA, flags=fl),
+                      o.step(robot_action=act, human_policy=_abi.HUMAN_ORCA, flags=fl), "wide step %d" % t)
+
+
 def test_observe_is_the_returned_observation():
     """ebc_observe of the current state = the ob / rotated rows the last step returned, and =
     the oracle's; right after reset it is env.reset()'s observation."""

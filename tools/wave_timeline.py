@@ -61,7 +61,7 @@ def main():
             epw = 64 // R if R <= 64 else 1
             rows_blocks = -(-E // epw)
             b1, b2, b3 = env_blocks, env_blocks + orca_blocks, env_blocks + orca_blocks + rows_blocks
-            parts = [("ENV", idx < b1), ("phase1 ORCA", (idx >= b1) & (idx < b2)),
+            parts = [("ENV", idx < b1), ("ORCA", (idx >= b1) & (idx < b2)),
                      ("ROWS", (idx >= b2) & (idx < b3)), ("STATE", idx >= b3)]
         else:
             parts = [(TAGS[tag], np.ones(len(idx), bool))]
@@ -86,13 +86,16 @@ def report(np, name, rows, base):
     edges = np.arange(0, us(r1.max()) + 1.0, 1.0)
     print("   resident waves at t = 0, 1, 2 ... us: " + " ".join(str(int(((us(r0) <= x) & (us(r1) > x)).sum())) for x in edges))
     print("   started by t:                        " + " ".join(str(int((us(r0) <= x).sum())) for x in edges))
+    if name == "ORCA":
+        last = np.argsort(r1)[-8:]
+        print("   the 8 waves that ended last (start us, lifetime us): " + " ".join("(%.1f, %.1f)" % (us(r0[q]), life[q]) for q in last))
     if name == "STATE" and rows[:, 5].any():
         c0 = rows[:, 2].astype(np.int64)
         mk = rows[:, 5:9].astype(np.int64)
         segs = [mk[:, 0] - c0, mk[:, 1] - mk[:, 0], mk[:, 2] - mk[:, 1], mk[:, 3] - mk[:, 2]]
         names = ["start->loads ready", "waiting", "wait->moved state stored", "restart scene stored"]
         print("   cycles mean / p90: " + ", ".join("%s %.0f / %.0f" % (n, v.mean(), np.percentile(v, 90)) for n, v in zip(names, segs)))
-    if name == "phase1 ORCA" and rows[:, 5].any():
+    if name == "ORCA" and rows[:, 5].any():
         c0 = rows[:, 2].astype(np.int64)
         marks = rows[:, 5:10].astype(np.int64) - c0[:, None]
         total = cyc
