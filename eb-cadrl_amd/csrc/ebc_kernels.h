@@ -7,14 +7,13 @@
 //                              (ENV, ORCA, ROWS, STATE) that meet through mailbox words.
 //   step_kernel<POLICY,T>      humans on the linear policy or with supplied / cached velocities:
 //                              one launch, service_env + service_commit in the same wave.
-// (A fused single-launch ORCA step -- service wave + ORCA waves per workgroup with an LDS
-// hand-off -- was built and measured: never faster than the split form on MI355X once the
-// service chain was cut down, and 1.6x slower at 4096 x 10; see DESIGN.md.)
+// (A first fused form -- service wave + ORCA waves per WORKGROUP with an LDS hand-off -- was 1.6x
+// slower than two launches at 4096 x 10; roles as separate one-wave workgroups are not: DESIGN.md.)
 //   orca_kernel<GS>     ORCA alone -> hact (look-ahead prelude)
 //   lookahead_kernel<T> the |A|-way onestep_lookahead sweep (multi_human_rl.py:38-61).
 //
 // HBM layout: struct-of-arrays [E][N] per human field (lane = e*N + i -> contiguous wave
-// accesses), robot [E][9], time [E], grid [E][G][2] u64.
+// accesses), robot [E][9] (two buffers), time [E], grid per pool slot [G][2] u64.
 #pragma once
 
 #include "ebc_device.h"
