@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one ebc_step call (phase 1 + phase 2 launches) over the rank's scene batch: ORCA for every human,
+A "step" is one ebc_step call (one HIP launch) over the rank's scene batch: ORCA for every human,
 kinematics, swept collisions, grid window, reward, rotated observation — inputs resident in
 HBM, outputs left in HBM.  Scenes are independent, so ranks own disjoint env slices and the
 data path has no collective (weak scaling: per-GPU batch fixed); torch.distributed (RCCL) only

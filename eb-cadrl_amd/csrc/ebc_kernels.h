@@ -106,7 +106,7 @@ struct LookIO {
   float *rows;
 };
 
-// The float tile entry of one human (orca.py:110-140): written by reset and by phase 2.
+// The float tile entry of one human (orca.py:110-140): written by reset and by the wave that moves the human.
 __device__ __forceinline__ void store_tile(const EbcParams &p, const DevState &s, size_t k, double px,
                                            double py, double vx, double vy, double gx, double gy,
                                            double rad, double vpref) {
@@ -962,9 +962,27 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   EBC_MARK(0);
   // wait for this wave's humans (every ORCA group of these envs has then read the tile and the
   // robot), for the envs' robot-side result, and for the ROWS waves to have read the old state
-  const unsigned long long v = mailbox_wait(vbox, m.env_ok, (unsigned long long)EBC_SLOT_EMPTY, s.fault);
-  const unsigned d = mailbox_wait(done_box, m.env_ok, 0u, s.fault);
-  if (wait_rows) mailbox_wait(loaded_box, m.env_ok, 0u, s.fault);
+  // (one loop for the three boxes: a poll is a memory round trip, three in a row were 2 us of the step)
+  unsigned long long v = EBC_SLOT_EMPTY;
+  unsigned d = 0;
+  {
+    bool wv = m.env_ok, wd = m.env_ok, wr = m.env_ok && wait_rows;
+    for (unsigned spins = 0;; ++spins) {
+      unsigned r = 1;
+      if (wv) v = __hip_atomic_load(vbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wd) d = __hip_atomic_load(done_box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (wr) r = __hip_atomic_load(loaded_box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wv = wv && v == EBC_SLOT_EMPTY;
+      wd = wd && d == 0;
+      wr = wr && r == 0;
+      if (!__any(wv || wd || wr)) break;
+      if (spins > EBC_SPIN_LIMIT) {
+        if (wv || wd || wr) atomicOr(s.fault, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
   EBC_MARK(1);
   if (!m.env_ok) return;
   mailbox_put(vbox, (unsigned long long)EBC_SLOT_EMPTY);

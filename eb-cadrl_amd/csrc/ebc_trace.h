@@ -51,7 +51,9 @@ struct WaveTrace {
       o[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
       const unsigned *box = wave_trace_lds();
       for (int k = 0; k < 6; ++k) o[5 + k] = box[k] ? c0 + (unsigned)(box[k] - (unsigned)c0) : 0;  // marks, shader cycles
-      for (int k = 0; k < 5; ++k) o[11 + k] = box[8 + k];
+      const unsigned long long prev_lp3 = o[12];  // the previous launch's count: how persistent is "hard"?
+      for (int k = 0; k < 4; ++k) o[11 + k] = box[8 + k];
+      o[15] = prev_lp3;
     }
   }
 };

@@ -71,6 +71,25 @@ def main():
         for name, sel in parts:
             if sel.any():
                 report(np, name, rows[sel], launch0 if tag == 3 and launch0 is not None else base_all)
+        if tag == 2 and len(idx) == b3 + env_blocks:
+            # what each STATE wave waited for: the ORCA waves of its envs and its ENV wave
+            end = (rows[:, 1].astype(np.int64) - base_all) / 100.0
+            start = (rows[:, 0].astype(np.int64) - base_all) / 100.0
+            hpw, epb = 64 // gs, 64 // batch.N
+            lag, info = [], []
+            for sb in range(env_blocks):
+                h0, h1 = sb * epb * batch.N, min((sb + 1) * epb, E) * batch.N - 1
+                o0, o1 = b1 + h0 // hpw, b1 + h1 // hpw
+                ready_orca = end[o0:o1 + 1].max()
+                ready = max(ready_orca, end[sb])
+                lag.append(end[b3 + sb] - ready)
+                info.append((end[b3 + sb], ready_orca, end[sb], start[b3 + sb]))
+            lag = np.array(lag)
+            print("STATE end minus (its last ORCA wave's end, its ENV wave's end): p10/p50/p90/max %.2f %.2f %.2f %.2f us" % (
+                np.percentile(lag, 10), np.percentile(lag, 50), np.percentile(lag, 90), lag.max()))
+            last = np.argsort([q[0] for q in info])[-6:]
+            print("   the 6 STATE waves that ended last (end, last ORCA end, ENV end, own start): " +
+                  " ".join("(%.1f %.1f %.1f %.1f)" % info[q] for q in last))
 
 
 def report(np, name, rows, base):
@@ -108,6 +127,9 @@ def report(np, name, rows, base):
             print("   %s: cycles per segment " % label + ", ".join(
                 "%s %.0f" % (n, seg[pick, q].mean()) for q, n in enumerate(names)) +
                 "; LP1 calls %.1f, LP3 entered %.2f, LP3 rounds %.1f" % (lp1[pick].mean(), lp3[pick].mean(), lp3it[pick].mean()))
+        prev = rows[:, 15].astype(np.int64)
+        both = ((lp3 > 0) & (prev > 0)).sum()
+        print("   waves entering LP3 this launch %d, the launch before %d, both %d (of %d waves)" % ((lp3 > 0).sum(), (prev > 0).sum(), both, len(lp3)))
         print("   LP1 calls per wave: mean %.2f p50 %d p90 %d max %d; waves entering LP3: %.1f%%" % (
             lp1.mean(), np.percentile(lp1, 50), np.percentile(lp1, 90), lp1.max(), 100.0 * (lp3 > 0).mean()))
 
