@@ -38,6 +38,7 @@ struct ScenePool {
   double *spx, *spy, *sradius;
   uint64_t *grid;  // nullptr: free maps
   double *robot;
+  float2 *pref;    // [slots][N] ORCA preferred velocity of the scene's humans (float tile, orca.py:136-140)
 };
 
 struct DevState {
@@ -50,6 +51,7 @@ struct DevState {
   int *grid_scene;  // [E] pool slot whose occupancy grid env e uses (pool.grid is null when every map is free)
   double *robot;    // [E][9] FullState order
   double *robot_n;  // [E][9] the fused ORCA step writes the robots' next state here; the host then swaps the two
+  double *robot_pub;  // [E][9] the same values for the ROWS role, in a place no restart overwrites
   double *time;   // [E] global_time
   double *arrival;
   uint8_t *done;  // terminal flag of the last step
@@ -61,7 +63,7 @@ struct DevState {
   unsigned long long *vel_rows;   // [E][N] the same for the ROWS role
   unsigned *env_done;             // [E] ENV -> STATE: 1 + done
   unsigned *rows_loaded;          // [E] ROWS -> STATE: pre-step state has been read (1)
-  unsigned *robot_ready;          // [E] ENV -> ROWS: robot_n[e] holds this step's result (= the launch's epoch; never reset)
+  unsigned *robot_ready;          // [E] ENV -> ROWS: robot_pub[e] holds this step's result (= the launch's epoch; never reset)
   unsigned *fault;                // [1] a poll gave up (protocol broken); ebc_synchronize reports it
   ScenePool pool;  // where auto-reset takes an env's next scene from
   // what rvo2 would hold for the current state (float), one 32-byte record per human slot:
@@ -115,6 +117,17 @@ __device__ __forceinline__ void store_tile(const EbcParams &p, const DevState &s
   s.tile[2 * k] = make_float4((float)px, (float)py, (float)vx, (float)vy);
   // orca.py:116, :122-126 (radius), :117 (maxSpeed)
   s.tile[2 * k + 1] = make_float4((float)(rad + 0.01 + p.orca_safety_space), (float)vpref, prefx, prefy);
+}
+
+// The preferred velocities of pool scenes [first, first + count) (in human slots), so that a
+// restart copies them instead of redoing a double sqrt and two divisions inside the step.
+__global__ __launch_bounds__(256) void pool_pref_kernel(DevState s, size_t first, size_t count) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= count) return;
+  const size_t k = first + q;
+  float prefx, prefy;
+  orca_pref_velocity(s.pool.px[k], s.pool.py[k], s.pool.gx[k], s.pool.gy[k], prefx, prefy);
+  s.pool.pref[k] = make_float2(prefx, prefy);
 }
 
 __global__ __launch_bounds__(256) void tile_kernel(EbcParams p, DevState s) {
@@ -336,7 +349,8 @@ __device__ __forceinline__ CommitPre preload_commit(const DevState &s, const Ste
   for (int q = 0; q < 9; ++q) c.robot[q] = 0;
   if (io.auto_reset && m.env_ok) {
     const ScenePool &P = s.pool;
-    c.cursor = P.cursor[m.ee];
+    // without a custom pool an env restarts from its own slot: no load in front of the scene's
+    c.cursor = P.P > 0 ? P.cursor[m.ee] : (int)m.ee;
     const size_t src = (size_t)c.cursor * s.N + m.i;
     c.n_humans = P.n_humans[c.cursor];
     c.px = P.px[src]; c.py = P.py[src]; c.vx = P.vx[src]; c.vy = P.vy[src];
@@ -478,9 +492,8 @@ __device__ __forceinline__ void robot_advance(const EbcParams &p, double *rb, do
 __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s, const StepIO &io,
                                            const LaneMap &m, const HumanRegs &h, double rb[9],
                                            double gtime, int lane, unsigned epoch = 0) {
-  __shared__ double sh_d[EBC_WAVE];
+  __shared__ double sh_cand[3][EBC_WAVE];  // per collision class: this lane's distance, if it counts
   __shared__ double sh_ract[EBC_WAVE][2];
-  __shared__ uint8_t sh_type[EBC_WAVE];
   const double dt = p.time_step;
   int grid_slot = (m.leader && s.pool.grid) ? s.grid_scene[m.ee] : 0;
   pin(grid_slot);
@@ -492,6 +505,7 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
       a0 = io.robot_action[2 * m.ee];
       a1 = io.robot_action[2 * m.ee + 1];
     }
+    EBC_MARK(1);
     sh_ract[m.el][0] = a0;
     sh_ract[m.el][1] = a1;
     if (epoch) {
@@ -502,9 +516,15 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
       // Device-scope stores go through to memory; the flag is stored (below, after the distance
       // work) once they have been acknowledged.  (An agent-scope release FENCE would do, but on this
       // part it writes back the whole L2 of the XCD: it doubled the step time.)
-      double *o = s.robot_n + m.ee * 9;
+      // Two copies: robot_n is what the next step reads (a restart overwrites it later in this
+      // launch, so this store must already be in memory by then: device scope as well); robot_pub
+      // is what the ROWS role builds this step's observation frame from.
+      double *o = s.robot_n + m.ee * 9, *o2 = s.robot_pub + m.ee * 9;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) __hip_atomic_store(o + c, rn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int c = 0; c < 9; ++c) {
+        __hip_atomic_store(o + c, rn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o2 + c, rn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
   wave_sync();
@@ -517,31 +537,43 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
     rvx = a0 * cos(a1 + rb[8]);
     rvy = a0 * sin(a1 + rb[8]);
   }
-  sh_d[lane] = m.active ? closest_dist(h.px, h.py, h.vx, h.vy, h.rad, rb[0], rb[1], rb[4], rvx, rvy, dt) : 0.0;
-  sh_type[lane] = (uint8_t)h.type;
+  // ordered per-type reduction with break at the first hit (env.py:303-313), without the serial
+  // walk: per type, the first colliding human of the env comes out of a ballot; a human counts
+  // for the type's minimum distance when it lies before that one
+  const double d = m.active ? closest_dist(h.px, h.py, h.vx, h.vy, h.rad, rb[0], rb[1], rb[4], rvx, rvy, dt) : 0.0;
+  const bool hit = m.active && d < 0;
+  const int base = lane - m.i;  // first lane of this env
+  int coll_t[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const unsigned long long hm = (__ballot(hit && h.type == t) >> base) & (s.N >= 64 ? ~0ull : ((1ull << s.N) - 1));
+    const int first = hm ? __ffsll((long long)hm) - 1 : s.N;
+    coll_t[t] = hm != 0;
+    sh_cand[t][lane] = (m.active && h.type == t && !hit && m.i < first) ? d : INFINITY;
+  }
   wave_sync();
+  EBC_MARK(2);
   if (epoch) {  // the stores of robot_n went out a distance computation ago: this wait is short
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (m.leader) mailbox_put(s.robot_ready + m.ee, epoch);
   }
   if (!m.leader) return 0;
-  // ordered per-type reduction with break at the first hit (env.py:303-313)
   double dm0 = INFINITY, dm1 = INFINITY, dm2 = INFINITY;
-  int c0 = 0, c1 = 0, c2 = 0;
-  for (int q = 0; q < m.n; ++q) {
-    const int t = sh_type[lane + q];
-    const double d = sh_d[lane + q];
-    const bool hit = d < 0;
-    if (t == 0 && !c0) { c0 = hit; dm0 = (!hit && d < dm0) ? d : dm0; }
-    if (t == 1 && !c1) { c1 = hit; dm1 = (!hit && d < dm1) ? d : dm1; }
-    if (t == 2 && !c2) { c2 = hit; dm2 = (!hit && d < dm2) ? d : dm2; }
+  const int c0 = coll_t[0], c1 = coll_t[1], c2 = coll_t[2];
+  for (int q = 0; q < m.n; ++q) {  // independent loads: no branch between them
+    const double d0 = sh_cand[0][lane + q], d1 = sh_cand[1][lane + q], d2 = sh_cand[2][lane + q];
+    dm0 = d0 < dm0 ? d0 : dm0;
+    dm1 = d1 < dm1 ? d1 : dm1;
+    dm2 = d2 < dm2 ? d2 : dm2;
   }
   const double dmin[3] = {dm0, dm1, dm2};
+  EBC_MARK(3);
   double nx, ny;
   robot_next_position(rb, p.robot_kinematics, a0, a1, dt, nx, ny);
   int coll[4] = {c0, c1, c2, 0};
   coll[3] = grid_collision(s.pool.grid ? s.pool.grid + (size_t)grid_slot * s.G * 2 : nullptr, s.G, p.map_size_m,
                            p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
+  EBC_MARK(4);
   const RewardOut ro = reward_compute(p, nx, ny, rb[5], rb[6], rb[4], a1, gtime, dmin, coll);
   // Agent.step for the robot (agent.py:202-228)
   rb[0] = nx;
@@ -810,6 +842,7 @@ __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &
   pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type); pin(gtime); pin(done_box);
 #pragma unroll
   for (int q = 0; q < 9; ++q) pin(rb[q]);
+  EBC_MARK(0);
   const int done = service_env(p, s, io, m, h, rb, gtime, lane, epoch);
   if (m.leader) mailbox_put(done_box, 1u + (unsigned)done);
 }
@@ -872,19 +905,18 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
     }
     unsigned long long *vbox = s.vel_rows + k;
     pin(opx); pin(opy); pin(orad); pin(otype); pin(vbox); pin(n); pin(ns);
+    // every pre-step value this env's rows need is in registers: STATE may overwrite the state
+    if (env_ok && slot + stride >= R && first == 0) mailbox_put(s.rows_loaded + ee, 1u);
     if (slot == first) {
       // the robot's next state: the ENV role publishes it early in its run (service_env)
       mailbox_wait_epoch(s.robot_ready + ee, env_ok, epoch, s.fault);
       double rb[9];  // device-scope loads, issued after the flag was seen: they do not come from a stale cache line
 #pragma unroll
       for (int c = 0; c < 9; ++c)
-        rb[c] = env_ok ? __hip_atomic_load(s.robot_n + ee * 9 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        rb[c] = env_ok ? __hip_atomic_load(s.robot_pub + ee * 9 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       f = rot_frame(rb, p.rotate_unicycle);
       pin(f.px); pin(f.py); pin(f.dg);
     }
-    // every value of this step's state that this env's rows need is in registers: STATE may
-    // overwrite the humans, and on a restart robot_n[e]
-    if (env_ok && slot + stride >= R && first == 0) mailbox_put(s.rows_loaded + ee, 1u);
     const bool valid = human ? slot < n : slot - N < ns;
     const int row = human ? (valid ? slot : ns + slot) : (valid ? n + slot - N : slot);
     const unsigned long long v = mailbox_wait(vbox, env_ok && human, (unsigned long long)EBC_SLOT_EMPTY, s.fault);
@@ -938,14 +970,16 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   io_state.obs_rotated = nullptr;
   unsigned long long *vbox = s.vel_state + m.k;
   unsigned *done_box = s.env_done + m.ee, *loaded_box = s.rows_loaded + m.ee;
-  // The restart scene (cursor, then the scene: two round trips) while there is nothing else to
-  // do, and what can be derived from it ahead of time: its preferred velocity (a double sqrt and
-  // two divisions) and, parked in LDS, the restart robot.
+  // The restart scene while there is nothing else to do (behind the cursor when a custom pool is
+  // installed), its preferred velocity (worked out when the pool was uploaded) and, parked in LDS,
+  // the restart robot.
   CommitPre pre = preload_commit<false>(s, io_state, m);
   float rprefx = 0, rprefy = 0;
   const bool parked = m.el < EBC_RBN_ENVS;
   if (io.auto_reset && m.env_ok) {
-    orca_pref_velocity(pre.px, pre.py, pre.gx, pre.gy, rprefx, rprefy);
+    const float2 rp = s.pool.pref[(size_t)pre.cursor * s.N + m.i];
+    rprefx = rp.x;
+    rprefy = rp.y;
     if (m.leader && parked) {
       const double *src = s.pool.robot + (size_t)pre.cursor * 9;
 #pragma unroll
@@ -1009,13 +1043,13 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
       const double dx = h.gx - h.px, dy = h.gy - h.py;
       const double dist = norm2(dx, dy);
       if (h.arrival == 0 && dist < h.rad) h.arrival = tnew;
-      float prefx, prefy;
-      orca_pref_from(dx, dy, dist, prefx, prefy);
       s.px[m.k] = h.px;
       s.py[m.k] = h.py;
       s.vx[m.k] = ax;
       s.vy[m.k] = ay;
       s.arrival[m.k] = h.arrival;
+      float prefx, prefy;
+      orca_pref_from(dx, dy, dist, prefx, prefy);
       tile[0] = make_float4((float)h.px, (float)h.py, (float)ax, (float)ay);
       tile[1] = make_float4(tile_rad, tile_max, prefx, prefy);
     }

@@ -36,24 +36,35 @@ __device__ __forceinline__ void wave_count(int k) {
   if (wave_first_lane()) wave_trace_lds()[8 + k] += 1;
 }
 struct WaveTrace {
-  unsigned long long r0, c0;
   int tag;
+  // nothing is kept in registers between the two stamps (the step kernel runs at its register
+  // budget: two live 64-bit values would spill): the start goes straight to the row
   __device__ __forceinline__ explicit WaveTrace(int t) : tag(t) {
+#if EBC_WAVE_TRACE > 1
     if (threadIdx.x < 16) wave_trace_lds()[threadIdx.x] = 0;
-    r0 = __builtin_amdgcn_s_memrealtime();
-    c0 = __builtin_amdgcn_s_memtime();
+#endif
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long *o = wave_trace_row(t);
+    if (o && threadIdx.x == 0) {
+      o[0] = r0;
+      o[2] = c0;
+    }
   }
   __device__ __forceinline__ ~WaveTrace() {
     const unsigned long long r1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
     unsigned long long *o = wave_trace_row(tag);
     if (o && threadIdx.x == 0) {
-      o[0] = r0; o[1] = r1; o[2] = c0; o[3] = c1;
+      o[1] = r1;
+      o[3] = c1;
+#if EBC_WAVE_TRACE > 1
       o[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
       const unsigned *box = wave_trace_lds();
-      for (int k = 0; k < 6; ++k) o[5 + k] = box[k] ? c0 + (unsigned)(box[k] - (unsigned)c0) : 0;  // marks, shader cycles
+      const unsigned c0 = (unsigned)o[2];
+      for (int k = 0; k < 6; ++k) o[5 + k] = box[k] ? o[2] + (unsigned)(box[k] - c0) : 0;  // marks, shader cycles
       const unsigned long long prev_lp3 = o[12];  // the previous launch's count: how persistent is "hard"?
       for (int k = 0; k < 4; ++k) o[11 + k] = box[8 + k];
       o[15] = prev_lp3;
+#endif
     }
   }
 };

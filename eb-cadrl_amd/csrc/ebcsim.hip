@@ -265,6 +265,7 @@ int alloc_pool(Handle *h, int P) {
   G_(n_humans, slots, E); G_(px, PN, EN); G_(py, PN, EN); G_(vx, PN, EN); G_(vy, PN, EN); G_(gx, PN, EN);
   G_(gy, PN, EN); G_(radius, PN, EN); G_(v_pref, PN, EN); G_(type, PN, EN); G_(n_static, slots, E);
   G_(spx, PS, ES); G_(spy, PS, ES); G_(sradius, PS, ES); G_(robot, slots * 9, (size_t)E * 9);
+  G_(pref, PN, EN);
 #undef G_
   if (rc == EBC_OK) rc = get(&h->pool_grid_alloc, slots * h->s.G * 2, old_grid, (size_t)E * h->s.G * 2);
   pl.grid = (keep && old.grid) ? h->pool_grid_alloc : nullptr;
@@ -418,7 +419,7 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
 #define A_(field, cnt) if (rc == EBC_OK) rc = dev_alloc(h, &s.field, (cnt))
   A_(n_humans, n_envs); A_(px, EN); A_(py, EN); A_(vx, EN); A_(vy, EN); A_(gx, EN); A_(gy, EN);
   A_(radius, EN); A_(v_pref, EN); A_(type, EN); A_(n_static, n_envs); A_(spx, ES); A_(spy, ES);
-  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN);
+  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(robot_pub, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN);
   A_(tile, EN * 2);
   A_(done, n_envs); A_(hact, EN * 2);
   A_(vel_state, EN); A_(vel_rows, EN); A_(env_done, n_envs); A_(rows_loaded, n_envs); A_(robot_ready, n_envs); A_(fault, 1);
@@ -542,8 +543,10 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *sc) {
       if (pl.P == 0) HIP_TRY(hipMemcpy(pl.cursor + e, &e, sizeof(int), hipMemcpyHostToDevice));
     }
   }
-  {  // the float tile the ORCA waves read (orca.py:110-140), for the whole batch
+  {  // the float tile the ORCA waves read (orca.py:110-140), for the whole batch, and the preferred
+     // velocities of the reset slots
     const size_t EN = (size_t)s.E * N;
+    hipLaunchKernelGGL(ebc::pool_pref_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0, h->stream, h->s, (size_t)0, EN);
     hipLaunchKernelGGL(ebc::tile_kernel, dim3((unsigned)((EN + 255) / 256)), dim3(256), 0, h->stream, h->p, h->s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -570,6 +573,12 @@ int ebc_set_scene_pool(void *handle, const EbcScene *sc, int stride) {
                          pl.n_static + E, pl.spx + E * S, pl.spy + E * S, pl.sradius + E * S,
                          h->pool_grid_alloc + (size_t)E * s.G * 2, pl.robot + (size_t)E * 9};
   if ((rc = upload_scene(h, sc, nullptr, slot, false)) != EBC_OK) return rc;
+  {
+    const size_t first = (size_t)E * N, count = (size_t)P * N;
+    hipLaunchKernelGGL(ebc::pool_pref_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, h->s, first, count);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   pl.stride = stride % P;
   std::vector<int> cur(E);
   for (int e = 0; e < E; ++e) cur[e] = E + e % P;

@@ -234,6 +234,11 @@ int ebc_set_human_actions(void *handle, int location, const double *act);
  * (rl/policy/multi_human_rl.py:128-149).  ob [E][R][5], obs_rotated [E][R][T]; either may be NULL. */
 int ebc_observe(void *handle, int location, double *ob, float *obs_rotated);
 
+/* One env.step for every env (simulator/env.py:388-466), enqueued on the handle's stream.  With
+ * EBC_HUMAN_ORCA it is ONE kernel launch whose arguments change from call to call (the robot state
+ * is double-buffered and a launch counter travels with the launch): call it once per step; do not
+ * capture it in a HIP graph and replay it.  A broken hand-off inside that launch (never seen)
+ * surfaces as EBC_ERR_DEVICE from ebc_synchronize, not as a hang. */
 int ebc_step(void *handle, const EbcStepArgs *args);
 int ebc_lookahead(void *handle, const EbcLookaheadArgs *args);
 int ebc_get_state(void *handle, const EbcStateView *view);

@@ -105,15 +105,28 @@ def report(np, name, rows, base):
     edges = np.arange(0, us(r1.max()) + 1.0, 1.0)
     print("   resident waves at t = 0, 1, 2 ... us: " + " ".join(str(int(((us(r0) <= x) & (us(r1) > x)).sum())) for x in edges))
     print("   started by t:                        " + " ".join(str(int((us(r0) <= x).sum())) for x in edges))
+    if name == "ENV" and rows[:, 5].any():
+        c0 = rows[:, 2].astype(np.int64)
+        mk = rows[:, 5:10].astype(np.int64)
+        names = ["start->loads ready", "robot action", "distances", "ordered reduce", "grid window", "reward + outputs"]
+        segs = [mk[:, 0] - c0] + [mk[:, q + 1] - mk[:, q] for q in range(4)] + [cyc - (mk[:, 4] - c0)]
+        print("   cycles mean: " + ", ".join("%s %.0f" % (n, v.mean()) for n, v in zip(names, segs)))
     if name == "ORCA":
         last = np.argsort(r1)[-8:]
         print("   the 8 waves that ended last (start us, lifetime us): " + " ".join("(%.1f, %.1f)" % (us(r0[q]), life[q]) for q in last))
     if name == "STATE" and rows[:, 5].any():
         c0 = rows[:, 2].astype(np.int64)
         mk = rows[:, 5:9].astype(np.int64)
-        segs = [mk[:, 0] - c0, mk[:, 1] - mk[:, 0], mk[:, 2] - mk[:, 1], mk[:, 3] - mk[:, 2]]
-        names = ["start->loads ready", "waiting", "wait->moved state stored", "restart scene stored"]
-        print("   cycles mean / p90: " + ", ".join("%s %.0f / %.0f" % (n, v.mean(), np.percentile(v, 90)) for n, v in zip(names, segs)))
+        mhz = cyc / np.maximum(life, 1e-9)  # this wave's shader clock
+        at = lambda q: us(r0) + (mk[:, q] - c0) / mhz  # a mark as us on the launch's time axis
+        ready, woke, done_ = at(0), at(1), at(2)
+        pct = lambda v: "%.1f / %.1f / %.1f" % (np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90))
+        print("   on the launch's time axis, p10 / p50 / p90 us: own loads ready %s, mailboxes all full %s, state stored %s" % (
+            pct(ready), pct(woke), pct(done_)))
+        print("   mailboxes full -> stored: %s us" % pct(done_ - woke))
+        last = np.argsort(done_)[-6:]
+        print("   the 6 that stored last (start, loads ready, mailboxes full, stored): " + " ".join(
+            "(%.1f %.1f %.1f %.1f)" % (us(r0[q]), ready[q], woke[q], done_[q]) for q in last))
     if name == "ORCA" and rows[:, 5].any():
         c0 = rows[:, 2].astype(np.int64)
         marks = rows[:, 5:10].astype(np.int64) - c0[:, None]
