@@ -14,10 +14,16 @@ from . import _abi
 
 
 def _mlp(x, layers, last_relu):
+    """Linear (+ ReLU) stack.  On the GPU the bias and the ReLU ride in the GEMM's epilogue
+    (torch._addmm_activation -> hipBLASLt): same values, no separate pass over the activations."""
     for i, (w, b) in enumerate(layers):
-        x = torch.nn.functional.linear(x, w, b)
-        if i != len(layers) - 1 or last_relu:
-            x = torch.relu(x)
+        relu = i != len(layers) - 1 or last_relu
+        if relu and x.is_cuda and x.dim() == 2 and hasattr(torch, "_addmm_activation"):
+            x = torch._addmm_activation(b, x, w.t(), use_gelu=False)
+        else:
+            x = torch.nn.functional.linear(x, w, b)
+            if relu:
+                x = torch.relu(x)
     return x
 
 
@@ -69,11 +75,17 @@ class SarlValueNet(object):
             h1v = h1.view(B, R, -1)
             if valid is not None:
                 h1v = h1v * valid[:, :, None]
-            g = (h1v.sum(1, keepdim=True) / denom).expand(B, R, h1v.shape[2])
-            att_in = torch.cat([h1.view(B, R, -1), g], dim=2).reshape(B * R, -1)
+            g = h1v.sum(1) / (denom if isinstance(denom, float) else denom[:, 0, :])  # [B, H]: mean of the pair's rows
+            # attention layer 1 on cat([h1, g]) without building the concatenation: the g half of the
+            # weight acts once per pair, its result is added to every row of the pair
+            H = h1.shape[1]
+            w0, b0 = self.attention[0]
+            gterm = torch.nn.functional.linear(g, w0[:, H:], b0)  # [B, A1]
+            a1 = torch.nn.functional.linear(h1, w0[:, :H]).view(B, R, -1)
+            a1 = torch.relu_(a1.add_(gterm[:, None, :])).view(B * R, -1)
+            scores = _mlp(a1, self.attention[1:], False).view(B, R)
         else:
-            att_in = h1
-        scores = _mlp(att_in, self.attention, False).view(B, R)
+            scores = _mlp(h1, self.attention, False).view(B, R)
         e = torch.exp(scores) * (scores != 0).to(scores.dtype)  # the reference's masked softmax (sarl.py:69-70)
         if valid is not None:
             e = e * valid
