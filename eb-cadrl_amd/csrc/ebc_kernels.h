@@ -943,9 +943,11 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
 #pragma unroll
           for (int c = 0; c < T; ++c) out[c] = 0.0f;
         }
+        // streaming stores: nobody on the device reads the rows, and what is not left dirty in the
+        // L2s does not have to be written back before the next launch may start (-0.2 us per step)
         float *o = io.obs_rotated + (ee * R + row) * T;
 #pragma unroll
-        for (int c = 0; c < T; ++c) o[c] = out[c];
+        for (int c = 0; c < T; ++c) __builtin_nontemporal_store(out[c], o + c);
       }
     }
   }
