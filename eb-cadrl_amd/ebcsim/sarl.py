@@ -18,7 +18,8 @@ def _mlp(x, layers, last_relu):
     (torch._addmm_activation -> hipBLASLt): same values, no separate pass over the activations."""
     for i, (w, b) in enumerate(layers):
         relu = i != len(layers) - 1 or last_relu
-        if relu and x.is_cuda and x.dim() == 2 and hasattr(torch, "_addmm_activation"):
+        if (relu and x.is_cuda and x.dim() == 2 and not torch.is_grad_enabled()
+                and hasattr(torch, "_addmm_activation")):  # inference only: the fused op has no derivative
             x = torch._addmm_activation(b, x, w.t(), use_gelu=False)
         else:
             x = torch.nn.functional.linear(x, w, b)
@@ -82,7 +83,7 @@ class SarlValueNet(object):
             w0, b0 = self.attention[0]
             gterm = torch.nn.functional.linear(g, w0[:, H:], b0)  # [B, A1]
             a1 = torch.nn.functional.linear(h1, w0[:, :H]).view(B, R, -1)
-            a1 = torch.relu_(a1.add_(gterm[:, None, :])).view(B * R, -1)
+            a1 = torch.relu(a1 + gterm[:, None, :]).view(B * R, -1)
             scores = _mlp(a1, self.attention[1:], False).view(B, R)
         else:
             scores = _mlp(h1, self.attention, False).view(B, R)
