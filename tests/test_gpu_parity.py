@@ -246,6 +246,43 @@ def test_full_size_properties():
     np.testing.assert_allclose(st["global_time"], 40 * params.time_step, atol=1e-12)
 
 
+def test_full_size_parity_vs_oracle():
+    """The bench workload at its full size (4096 x 10, ORCA, walls, auto-reset, device-resident
+    outputs) against the oracle, every env every step: the one-launch step at full occupancy —
+    late-starting ORCA waves, consumer roles waiting for slots, restarts — must be what the scalar
+    CPU code computes (codes bit-exact, float64 state 1e-9, float32 rows 1e-5)."""
+    import torch
+    from oracle import oracle
+    z = load("traj_n10_walls_t17_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    params.time_limit = 6  # restarts from step 24 on, for every env that is still running
+    E = 4096
+    b, _ = _random_batch(_config_text(meta), [21000 + e for e in range(E)])
+    g = _env(params, E, b.N, b.S)
+    o = oracle.OracleEnv(params, E, b.N, b.S)
+    g.reset(b)
+    o.reset(b)
+    g.use_torch_stream()
+    outs = g.alloc_step_outputs(("reward", "done", "info", "obs_rotated", "human_action"))
+    fl = _abi.FLAG_AUTO_RESET
+    restarts = 0
+    for t in range(32):
+        g.step_device(outs, human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+        ref = o.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+        g.synchronize()
+        np.testing.assert_array_equal(outs["done"].cpu().numpy(), ref["done"], err_msg="step %d" % t)
+        np.testing.assert_array_equal(outs["info"].cpu().numpy(), ref["info"], err_msg="step %d" % t)
+        np.testing.assert_allclose(outs["reward"].cpu().numpy(), ref["reward"], atol=1e-9, rtol=0)
+        np.testing.assert_allclose(outs["human_action"].cpu().numpy(), ref["human_action"], atol=1e-9, rtol=0)
+        np.testing.assert_allclose(outs["obs_rotated"].cpu().numpy(), ref["obs_rotated"], atol=1e-5, rtol=1e-5)
+        restarts += int(ref["done"].sum())
+    assert restarts > E  # every env restarted at least once (time limit), many twice
+    sg, so = g.get_state(), o.get_state()
+    for k in sg:
+        np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
+
+
 def test_device_resident_step_matches_host_step():
     import torch
     z = load("traj_a5_linear_orcasub")
