@@ -1111,11 +1111,14 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   EBC_MARK(2);
 }
 
+// Waves per SIMD the register budget is set for.  6 (80 VGPRs) holds every role without spilling
+// up to 9-lane groups; wider groups unroll a longer ranking loop and get 5 (96): a spilled register
+// costs every wave of the launch its scratch set-up, one wave per SIMD less costs the late starters.
 #ifndef EBC_STEP_WAVES
-#define EBC_STEP_WAVES 6
+#define EBC_STEP_WAVES(GS) ((GS) <= 9 ? 6 : 5)
 #endif
 template <int GS, int T>
-__global__ __launch_bounds__(EBC_WAVE, EBC_STEP_WAVES) void orca_step_kernel(EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
+__global__ __launch_bounds__(EBC_WAVE, EBC_STEP_WAVES(GS)) void orca_step_kernel(EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
   const WaveTrace wt(2);
   constexpr size_t LDS = sizeof(RoleLds) > (size_t)OrcaLds<GS>::BYTES ? sizeof(RoleLds) : (size_t)OrcaLds<GS>::BYTES;
   __shared__ __align__(16) unsigned char lds[LDS];
