@@ -847,10 +847,21 @@ __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &
   if (m.leader) mailbox_put(done_box, 1u + (unsigned)done);
 }
 
+// Have a kernel argument in a scalar register HERE.  The compiler otherwise loads each field where
+// it is first used, inside the branch that uses it: four or five scalar-memory round trips in a
+// row before an ORCA wave issues its first vector load.
+template <typename Tp>
+__device__ __forceinline__ void sreg(const Tp &x) {
+  asm volatile("" ::"s"(x));
+}
+
 // ---- ORCA
 template <int GS>
 __device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s, unsigned char *scratch,
                                           unsigned block, bool rows, int lane) {
+  sreg(s.E); sreg(s.N); sreg(s.n_magic); sreg(s.n_shift); sreg(s.n_humans); sreg(s.tile); sreg(s.robot);
+  sreg(s.vel_state); sreg(s.vel_rows); sreg(s.range_sq); sreg(s.inv_time_horizon); sreg(s.inv_time_step);
+  sreg(p.robot_visible); sreg(p.orca_max_neighbors); sreg(p.orca_safety_space);
   constexpr int HPW = EBC_WAVE / GS;
   const int group = lane / GS, j = lane - group * GS;
   // 32-bit index math (E * N < 2^31 is checked at create)
