@@ -1377,8 +1377,9 @@ __global__ __launch_bounds__(EBC_LA_THREADS) void lookahead_kernel(EbcParams p, 
     const int body4 = cnt > head ? (cnt - head) / 4 : 0;
     for (int v = tid; v < body4; v += EBC_LA_THREADS) {
       const int f = head + 4 * v;
-      const float4 w = make_float4(tile[f], tile[f + 1], tile[f + 2], tile[f + 3]);
-      *reinterpret_cast<float4 *>(dst + f) = w;
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 w = {tile[f], tile[f + 1], tile[f + 2], tile[f + 3]};
+      __builtin_nontemporal_store(w, reinterpret_cast<f32x4 *>(dst + f));  // 400 MB that nothing on the device reads twice
     }
     const int tail0 = head + 4 * body4;
     if (tail0 + tid < cnt && tid < 4) dst[tail0 + tid] = tile[tail0 + tid];
