@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "ebc_kernels.h"
+#include "ebc_value_net.h"
 
 namespace {
 
@@ -772,6 +773,142 @@ int ebc_timing_read(void *handle, int reset, double *avg_ms, int64_t *launches) 
     h->ms_sum = 0;
     h->launches = 0;
   }
+  return EBC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------- value-network layers
+namespace {
+
+uint16_t bf16_rn(float v) {  // round to nearest even, as v_cvt_pk_bf16_f32
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf16_to_float(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float v;
+  memcpy(&v, &u, 4);
+  return v;
+}
+
+struct Mlp2 {
+  int device = 0, K0 = 0, H = 0, O = 0;
+  ebc::PackedLayer L1{}, L2{};
+  std::vector<void *> allocs;
+};
+
+// W [out][in] (torch Linear layout) -> A fragments of mfma_f32_32x32x16_bf16, split in hi / lo.
+// acc_order: the layer's input is an accumulator tile of the layer before (fragment element j of lane
+// half h in k-step s is row 16 s + 8 (j >> 2) + 4 h + (j & 3)); otherwise natural order 16 s + 8 h + j.
+int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool acc_order, ebc::PackedLayer *L) {
+  const int To = (out + 31) / 32, Ti = (in + 31) / 32;
+  std::vector<uint16_t> frag((size_t)To * Ti * 2 * 2 * 64 * 8);
+  for (int t = 0; t < To; ++t)
+    for (int u = 0; u < Ti; ++u)
+      for (int s = 0; s < 2; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int i = lane & 31, hh = lane >> 5;
+            const int k = acc_order ? 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3) : 16 * s + 8 * hh + j;
+            const int row = t * 32 + i, colk = u * 32 + k;
+            const float v = (row < out && colk < in) ? W[(size_t)row * in + colk] : 0.0f;
+            const uint16_t hi = bf16_rn(v), lo = bf16_rn(v - bf16_to_float(hi));
+            const size_t base = ((((size_t)t * Ti + u) * 2 + s) * 2) * 64 * 8;
+            frag[base + (size_t)lane * 8 + j] = hi;
+            frag[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+          }
+  std::vector<float> bias((size_t)To * 2 * 16, 0.0f);
+  for (int t = 0; t < To; ++t)
+    for (int hh = 0; hh < 2; ++hh)
+      for (int r = 0; r < 16; ++r) {
+        const int unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (unit < out) bias[((size_t)t * 2 + hh) * 16 + r] = b[unit];
+      }
+  void *df = nullptr, *db = nullptr;
+  HIP_TRY(hipMalloc(&df, frag.size() * 2));
+  m->allocs.push_back(df);
+  HIP_TRY(hipMalloc(&db, bias.size() * 4));
+  m->allocs.push_back(db);
+  HIP_TRY(hipMemcpy(df, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  L->frag = (const uint4 *)df;
+  L->bias = (const float *)db;
+  L->in_tiles = Ti;
+  L->out_tiles = To;
+  return EBC_OK;
+}
+
+template <int TI>
+int launch_mlp2(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y) {
+  const dim3 grid((unsigned)((M + 31) / 32)), block(64);
+#define ML_(TO) hipLaunchKernelGGL((ebc::mlp2_split_kernel<TI, TO>), grid, block, 0, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O)
+  switch (m->L2.out_tiles) {
+    case 1: ML_(1); break;
+    case 2: ML_(2); break;
+    case 3: ML_(3); break;
+    case 4: ML_(4); break;
+    case 5: ML_(5); break;
+    case 6: ML_(6); break;
+    case 7: ML_(7); break;
+    default: return fail(EBC_ERR_UNSUPPORTED, "mlp2: more than 224 outputs");
+  }
+#undef ML_
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
+                    const float *b2, void **out) {
+  if (!w1 || !b1 || !w2 || !b2 || !out) return fail(EBC_ERR_INVALID, "null argument");
+  if (K0 <= 0 || H <= 0 || O <= 0 || K0 > 224 || O > 224) return fail(EBC_ERR_UNSUPPORTED, "mlp2 dimensions");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(EBC_ERR_DEVICE, "no HIP device: libebcsim has no CPU fallback");
+  if (device_id < 0 || device_id >= count) return fail(EBC_ERR_INVALID, "device_id out of range");
+  HIP_TRY(hipSetDevice(device_id));
+  Mlp2 *m = new Mlp2();
+  m->device = device_id; m->K0 = K0; m->H = H; m->O = O;
+  int rc = pack_layer(m, w1, b1, H, K0, false, &m->L1);
+  if (rc == EBC_OK) rc = pack_layer(m, w2, b2, O, H, true, &m->L2);
+  if (rc != EBC_OK) {
+    for (void *ptr : m->allocs) (void)hipFree(ptr);
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return EBC_OK;
+}
+
+int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_out, float *y) {
+  Mlp2 *m = (Mlp2 *)mlp;
+  if (!m || !x || !y || M < 0) return fail(EBC_ERR_INVALID, "mlp2 forward arguments");
+  if (M == 0) return EBC_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t st = (hipStream_t)stream;
+  switch (m->L1.in_tiles) {
+    case 1: return launch_mlp2<1>(m, st, x, M, relu_out, y);
+    case 2: return launch_mlp2<2>(m, st, x, M, relu_out, y);
+    case 3: return launch_mlp2<3>(m, st, x, M, relu_out, y);
+    case 4: return launch_mlp2<4>(m, st, x, M, relu_out, y);
+    case 5: return launch_mlp2<5>(m, st, x, M, relu_out, y);
+    case 6: return launch_mlp2<6>(m, st, x, M, relu_out, y);
+    default: return launch_mlp2<7>(m, st, x, M, relu_out, y);
+  }
+}
+
+int ebc_mlp2_destroy(void *mlp) {
+  Mlp2 *m = (Mlp2 *)mlp;
+  if (!m) return EBC_OK;
+  for (void *ptr : m->allocs) (void)hipFree(ptr);
+  delete m;
   return EBC_OK;
 }
 

@@ -28,6 +28,36 @@ def _mlp(x, layers, last_relu):
     return x
 
 
+class _NativeMlp2(object):
+    """A two-layer block on the bf16 matrix cores with split operands (libebcsim ebc_mlp2_*)."""
+
+    def __init__(self, layers, device_index):
+        import ctypes as C
+        from . import _capi
+        (w1, b1), (w2, b2) = layers
+        self._L, self._C = _capi.lib(), C
+        self.K0, self.H, self.O = int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])
+        host = [t.detach().to("cpu", torch.float32).contiguous().numpy() for t in (w1, b1, w2, b2)]
+        self._h = C.c_void_p()
+        _capi.check(self._L.ebc_mlp2_create(int(device_index), self.K0, self.H, self.O, host[0].ctypes.data,
+                                            host[1].ctypes.data, host[2].ctypes.data, host[3].ctypes.data,
+                                            C.byref(self._h)))
+
+    def __call__(self, x, relu_out):
+        from . import _capi
+        x = x.contiguous()
+        y = torch.empty((x.shape[0], self.O), dtype=torch.float32, device=x.device)
+        _capi.check(self._L.ebc_mlp2_forward(self._h, torch.cuda.current_stream(x.device).cuda_stream,
+                                             x.data_ptr(), int(x.shape[0]), int(bool(relu_out)), y.data_ptr()))
+        return y
+
+    def __del__(self):
+        try:
+            self._L.ebc_mlp2_destroy(self._h)
+        except Exception:
+            pass
+
+
 class SarlValueNet(object):
     """rl/policy/sarl.py:9-82 (ValueNetwork), weights from its state_dict."""
 
@@ -50,6 +80,24 @@ class SarlValueNet(object):
         self.self_state_dim = self_state_dim
         self.input_dim = self.mlp1[0][0].shape[1]
         self.device = torch.device(device)
+        self._native = None  # built on first use: (mlp1, mlp2, attention[1:]) as fused two-layer blocks
+
+    def _native_blocks(self):
+        """The three two-layer stacks of the network as libebcsim blocks (inference on a HIP device,
+        float32 weights, the reference's layer counts); None when that does not apply."""
+        if getattr(self, "_native", ()) is None:  # nets assembled by hand (training) carry no blocks
+            ok = (self.device.type == "cuda" and self.dtype == torch.float32 and len(self.mlp1) == 2
+                  and len(self.mlp2) == 2 and len(self.attention) == 3 and self.with_global_state)
+            stacks = (self.mlp1, self.mlp2, self.attention[1:])
+            if ok and all(st[0][0].shape[1] <= 224 and st[1][0].shape[0] <= 224 for st in stacks):
+                idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+                try:
+                    self._native = tuple(_NativeMlp2(st, idx) for st in stacks)
+                except Exception:  # an unsupported shape: stay on the torch path
+                    self._native = ()
+            else:
+                self._native = ()
+        return getattr(self, "_native", ()) or None
 
     @classmethod
     def load(cls, path, device="cpu", **kw):
@@ -64,8 +112,13 @@ class SarlValueNet(object):
         B, R, T = rows.shape
         rows = rows.to(getattr(self, "dtype", torch.float32))
         self_state = rows[:, 0, :self.self_state_dim]
-        h1 = _mlp(rows.reshape(B * R, T), self.mlp1, True)
-        feat = _mlp(h1, self.mlp2, False).view(B, R, -1)
+        nat = None if torch.is_grad_enabled() or not rows.is_cuda else self._native_blocks()
+        if nat is not None:
+            h1 = nat[0](rows.reshape(B * R, T), True)
+            feat = nat[1](h1, False).view(B, R, -1)
+        else:
+            h1 = _mlp(rows.reshape(B * R, T), self.mlp1, True)
+            feat = _mlp(h1, self.mlp2, False).view(B, R, -1)
         if n_valid is None:
             valid = None
             denom = float(R)
@@ -84,7 +137,10 @@ class SarlValueNet(object):
             gterm = torch.nn.functional.linear(g, w0[:, H:], b0)  # [B, A1]
             a1 = torch.nn.functional.linear(h1, w0[:, :H]).view(B, R, -1)
             a1 = torch.relu(a1 + gterm[:, None, :]).view(B * R, -1)
-            scores = _mlp(a1, self.attention[1:], False).view(B, R)
+            if nat is not None:
+                scores = nat[2](a1, False).view(B, R)
+            else:
+                scores = _mlp(a1, self.attention[1:], False).view(B, R)
         else:
             scores = _mlp(h1, self.attention, False).view(B, R)
         e = torch.exp(scores) * (scores != 0).to(scores.dtype)  # the reference's masked softmax (sarl.py:69-70)

@@ -62,6 +62,7 @@ class SarlModule(torch.nn.Module):
         net.with_global_state, net.self_state_dim = self.with_global_state, self.self_state_dim
         net.input_dim = self._layout["mlp1"][0]
         net.device = next(self.parameters()).device
+        net._native = ()  # the weights change under training: no packed copies of them
         return net
 
     def forward(self, rows, n_valid=None):

@@ -252,6 +252,20 @@ int ebc_dims(void *handle, int32_t out[5]);
 int ebc_timing(void *handle, int enable);
 int ebc_timing_read(void *handle, int reset, double *avg_ms, int64_t *launches);
 
+/* ---- value-network layers (the consumer of ebc_lookahead's rows) -------------------------------
+ * A two-layer block of the reference's mlp() helper (rl/policy/cadrl.py:9-20: Linear + ReLU stacks;
+ * rl/policy/sarl.py:13-21 builds mlp1 / mlp2 / attention / mlp3 from it):
+ *     y = [relu] (W2 relu(W1 x + b1) + b2),   x [M][K0] -> y [M][O]   (float32, device)
+ * on the bf16 matrix cores with every float32 operand split in two bf16 numbers (three products kept):
+ * float32-grade results (tests/test_value_net.py: 4e-5 relative; 1.5e-5 on the value of the reference's
+ * decision runs) at several times the float32 GEMM rate, the hidden layer never leaving the registers.
+ * w1 [H][K0], b1 [H], w2 [O][H], b2 [O]: host pointers, torch.nn.Linear layout.  K0, O <= 224. */
+int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
+                    const float *b2, void **mlp_out);
+/* x, y: device pointers; stream: hipStream_t (NULL = the null stream); relu_out: ReLU on y. */
+int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_out, float *y);
+int ebc_mlp2_destroy(void *mlp);
+
 #ifdef __cplusplus
 }
 #endif

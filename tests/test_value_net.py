@@ -1,0 +1,48 @@
+"""Dense blocks of the SARL value network on the bf16 matrix cores with split operands
+(csrc/ebc_value_net.h) against torch float32."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def _lib():
+    from ebcsim import _capi
+    return _capi.lib()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K0,H,O,M,relu_out", [(17, 300, 200, 1000, 1), (13, 150, 100, 333, 1),
+                                               (200, 200, 100, 515, 0), (100, 100, 50, 64, 0),
+                                               (200, 200, 1, 2049, 0), (5, 7, 3, 31, 1)])
+def test_mlp2_split_bf16_matches_float32(K0, H, O, M, relu_out):
+    import torch
+    from ebcsim import _capi
+    L = _lib()
+    rs = np.random.RandomState(K0 * 1000 + H)
+    w1 = (rs.randn(H, K0) / np.sqrt(K0)).astype(np.float32)
+    b1 = rs.randn(H).astype(np.float32) * 0.1
+    w2 = (rs.randn(O, H) / np.sqrt(H)).astype(np.float32)
+    b2 = rs.randn(O).astype(np.float32) * 0.1
+    x = (rs.randn(M, K0) * 2).astype(np.float32)
+    h = C.c_void_p()
+    _capi.check(L.ebc_mlp2_create(0, K0, H, O, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data,
+                                  C.byref(h)))
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.zeros((M, O), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    _capi.check(L.ebc_mlp2_forward(h, None, xd.data_ptr(), M, relu_out, yd.data_ptr()))
+    torch.cuda.synchronize()
+    ref = np.maximum(x.astype(np.float64) @ w1.T.astype(np.float64) + b1, 0) @ w2.T.astype(np.float64) + b2
+    if relu_out:
+        ref = np.maximum(ref, 0)
+    got = yd.cpu().numpy()
+    f32 = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(torch.from_numpy(x), torch.from_numpy(w1), torch.from_numpy(b1))), torch.from_numpy(w2), torch.from_numpy(b2)).numpy()
+    if relu_out:
+        f32 = np.maximum(f32, 0)
+    err = np.abs(got - ref).max()
+    err32 = np.abs(f32 - ref).max()
+    scale = np.abs(ref).max()
+    # three bf16 products per f32 product: relative error per term ~2^-16; float32 itself is ~1e-6 here
+    assert err <= 4e-5 * max(scale, 1.0), (err, err32, scale)
+    _capi.check(L.ebc_mlp2_destroy(h))
