@@ -38,14 +38,6 @@ __device__ __forceinline__ Frag2 split8(const float (&v)[8]) {
   return f;
 }
 
-// acc += W * X for one k-step: the three leading terms of (Wh + Wl)(Xh + Xl), small ones first
-__device__ __forceinline__ f32x16 mfma_split(const Frag2 &w, const Frag2 &x, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.lo, x.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.hi, x.hi, acc, 0, 0, 0);
-  return acc;
-}
-
 // Packed layer: A fragments [out tile][in tile][k-step 0/1][hi, lo][lane][8 bf16] and the bias in
 // accumulator order [out tile][lane half][16].
 struct PackedLayer {
@@ -53,15 +45,6 @@ struct PackedLayer {
   const float *bias;
   int in_tiles, out_tiles;
 };
-
-__device__ __forceinline__ Frag2 load_weight(const PackedLayer &L, int t, int u, int s, int lane) {
-  const uint4 *p = L.frag + ((((size_t)t * L.in_tiles + u) * 2 + s) * 2) * 64 + lane;
-  const uint4 h = p[0], l = p[64];
-  Frag2 f;
-  f.hi = *reinterpret_cast<const bf16x8 *>(&h);
-  f.lo = *reinterpret_cast<const bf16x8 *>(&l);
-  return f;
-}
 
 __device__ __forceinline__ f32x16 bias_tile(const PackedLayer &L, int t, int lane) {
   const float4 *b = reinterpret_cast<const float4 *>(L.bias + ((size_t)t * 2 + (lane >> 5)) * 16);
@@ -85,15 +68,48 @@ __device__ __forceinline__ void tile_frags(const f32x16 &acc, bool relu, Frag2 (
   }
 }
 
-// Y = act(W2 * relu(W1 * X + b1) + b2), one wave per tile of 32 rows of X [M][K0] (K0 <= 32 TI).
-// TI / TO: input / output tiles (compile time: they index registers); the hidden tiles stream.
-template <int TI, int TO>
-__global__ __launch_bounds__(64) void mlp2_split_kernel(const float *X, int M, int K0, PackedLayer L1, PackedLayer L2,
-                                                       int relu_out, float *Y, int O) {
-  const int lane = threadIdx.x, col = lane & 31, half = lane >> 5;
-  const int m = blockIdx.x * 32 + col;
+// Y = act(W2 * relu(W1 * X + b1) + b2) for X [M][K0] (K0 <= 32 TI), a workgroup of NW waves, one
+// 32-row tile per wave.  TI / TO: input / output tiles (compile time: they index registers); the
+// hidden tiles stream: each is made, turned into fragments and consumed.  The weights of a hidden tile
+// are staged once per workgroup in LDS — by global_load_lds, 1 KB per wave instruction, no registers in
+// between — and double-buffered: while the waves work on hidden tile u from one buffer, tile u + 1
+// arrives in the other.  (With the weights coming from L2 per wave and per k-step a wave spent nine
+// tenths of its time waiting for them.)
+// NW waves per workgroup: 4 when two workgroups' weight buffers fit a CU's LDS side by side, else 8
+// (two waves per SIMD either way: one's conversions run under the other's MFMAs).
+template <int TI, int TO, int NW>
+__global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_wg_kernel(const float *X, int M, int K0, PackedLayer L1,
+                                                           PackedLayer L2, int relu_out, float *Y, int O) {
+  extern __shared__ uint4 wbuf[];  // [2][PER_U] weights, then the hidden layer's biases
+  constexpr int PART = 64;                          // uint4 per fragment half (hi or lo) = 1 KB
+  constexpr int PER_U = (TI + TO) * 2 * 2 * PART;   // uint4 per hidden tile: its L1 row block + its L2 column block
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int m = (blockIdx.x * NW + wave) * 32 + col;
+  const int hidden_tiles = L1.out_tiles;
+  auto stage = [&](int u, int buf) {  // fragment halves p = wave, wave + NW, ...: one wave instruction each
+    for (int pp = wave; pp < (TI + TO) * 4; pp += NW) {
+      const int blk = pp >> 2, s = (pp >> 1) & 1, part = pp & 1;
+      const uint4 *src = blk < TI ? L1.frag + ((((size_t)u * TI + blk) * 2 + s) * 2 + part) * PART
+                                  : L2.frag + ((((size_t)(blk - TI) * hidden_tiles + u) * 2 + s) * 2 + part) * PART;
+      uint4 *dst = wbuf + (size_t)buf * PER_U + (size_t)pp * PART;
+      // As an asm statement: the builtin makes the compiler drain every outstanding load before the
+      // next LDS read (it cannot tell the two buffers apart), which is the overlap this kernel is
+      // built for.  M0 = the wave-uniform LDS byte address; each lane supplies its source address.
+      unsigned keep;
+      const uint4 *gsrc = src + lane;
+      const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst);  // wave-uniform: a scalar register
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  // No ordinary global load inside the loop: while a global_load_lds is in flight the compiler waits
+  // for ALL outstanding loads at the next use of a load result, and the overlap would be gone.  The
+  // hidden biases therefore wait in LDS.
+  float *hbias = reinterpret_cast<float *>(wbuf + 2 * PER_U);
+  for (int q = threadIdx.x; q < hidden_tiles * 32; q += 64 * NW) hbias[q] = L1.bias[q];
+  stage(0, 0);
   // the input tile as B fragments, natural k order: element j of k-step s is k = 16 s + 8 half + j
-  Frag2 x[TI][2];
+  Frag2 x[TI][2][1];
 #pragma unroll
   for (int u = 0; u < TI; ++u)
 #pragma unroll
@@ -101,34 +117,93 @@ __global__ __launch_bounds__(64) void mlp2_split_kernel(const float *X, int M, i
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int k = u * 32 + 16 * s + 8 * half + j;
-        v[j] = (m < M && k < K0) ? X[(size_t)m * K0 + k] : 0.0f;
+        const int kk = u * 32 + 16 * s + 8 * half + j;
+        v[j] = (m < M && kk < K0) ? X[(size_t)m * K0 + kk] : 0.0f;
       }
-      x[u][s] = split8(v);
+      x[u][s][0] = split8(v);
     }
-  f32x16 out[TO];
+  f32x16 out[TO][1];
 #pragma unroll
-  for (int t = 0; t < TO; ++t) out[t] = bias_tile(L2, t, lane);
-  for (int u = 0; u < L1.out_tiles; ++u) {  // hidden tile u: made, turned into fragments, consumed
-    f32x16 hid = bias_tile(L1, u, lane);
+  for (int t = 0; t < TO; ++t) out[t][0] = bias_tile(L2, t, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count the asm loads
+  __syncthreads();
+  for (int u = 0; u < hidden_tiles; ++u) {
+    const int buf = u & 1;
+    if (u + 1 < hidden_tiles) stage(u + 1, buf ^ 1);
+    const uint4 *w = wbuf + (size_t)buf * PER_U + lane;
+    auto frag = [&](int blk, int s) {
+      const uint4 h = w[((blk * 2 + s) * 2) * PART], l = w[((blk * 2 + s) * 2 + 1) * PART];
+      Frag2 f;
+      f.hi = *reinterpret_cast<const bf16x8 *>(&h);
+      f.lo = *reinterpret_cast<const bf16x8 *>(&l);
+      return f;
+    };
+    // A dependent MFMA waits for the one before it (64 cycles against a 32-cycle issue interval), so
+    // consecutive MFMAs go to different accumulators: the hidden tile collects its three kinds of
+    // terms in three accumulators (summed small-first at the end), the output tiles take turns.
+    f32x16 hA = {}, hB = {}, hC;
+    {
+      const float4 *hb = reinterpret_cast<const float4 *>(hbias + (u * 2 + half) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = hb[q];
+        hC[4 * q] = v.x; hC[4 * q + 1] = v.y; hC[4 * q + 2] = v.z; hC[4 * q + 3] = v.w;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) hid = mfma_split(load_weight(L1, u, i, s, lane), x[i][s], hid);
+      for (int s = 0; s < 2; ++s) {
+        const Frag2 wf = frag(i, s);
+        hA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.lo, x[i][s][0].hi, hA, 0, 0, 0);
+        hB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].lo, hB, 0, 0, 0);
+        hC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].hi, hC, 0, 0, 0);
+      }
+    f32x16 hid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[r] = (hA[r] + hB[r]) + hC[r];
     Frag2 hf[2];
     tile_frags(hid, true, hf);
 #pragma unroll
-    for (int t = 0; t < TO; ++t)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int s = 0; s < 2; ++s) out[t] = mfma_split(load_weight(L2, t, u, s, lane), hf[s], out[t]);
+      for (int t0 = 0; t0 < TO; t0 += 4) {  // four output tiles at a time: enough independent MFMAs, few registers
+        constexpr int C = 4;
+        Frag2 wf[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          if (t0 + c < TO) wf[c] = frag(TI + t0 + c, s);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          if (t0 + c < TO) out[t0 + c][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c].lo, hf[s].hi, out[t0 + c][0], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          if (t0 + c < TO) out[t0 + c][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c].hi, hf[s].lo, out[t0 + c][0], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          if (t0 + c < TO) out[t0 + c][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c].hi, hf[s].hi, out[t0 + c][0], 0, 0, 0);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile u + 1 has landed ...
+    __syncthreads();                                   // ... and everybody's; buffer `buf` is free
   }
   if (m < M) {
+    const bool vec = (O & 3) == 0;  // registers 4g .. 4g+3 are four consecutive units: one 16-byte store
 #pragma unroll
     for (int t = 0; t < TO; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (unit < O) Y[(size_t)m * O + unit] = relu_out ? fmaxf(out[t][r], 0.0f) : out[t][r];
+      for (int g = 0; g < 4; ++g) {
+        const int unit = t * 32 + 8 * g + 4 * half;
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = relu_out ? fmaxf(out[t][0][4 * g + c], 0.0f) : out[t][0][4 * g + c];
+        float *dst = Y + (size_t)m * O + unit;
+        if (vec && unit + 3 < O) {
+          *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (unit + c < O) dst[c] = v[c];
+        }
       }
   }
 }

@@ -842,23 +842,35 @@ int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool ac
   return EBC_OK;
 }
 
-template <int TI>
-int launch_mlp2(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y) {
-  const dim3 grid((unsigned)((M + 31) / 32)), block(64);
-#define ML_(TO) hipLaunchKernelGGL((ebc::mlp2_split_kernel<TI, TO>), grid, block, 0, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O)
-  switch (m->L2.out_tiles) {
-    case 1: ML_(1); break;
-    case 2: ML_(2); break;
-    case 3: ML_(3); break;
-    case 4: ML_(4); break;
-    case 5: ML_(5); break;
-    case 6: ML_(6); break;
-    case 7: ML_(7); break;
-    default: return fail(EBC_ERR_UNSUPPORTED, "mlp2: more than 224 outputs");
+template <int TI, int TO>
+int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y) {
+  // NW waves per workgroup, a 32-row tile each; the weights of one hidden tile twice in LDS
+  constexpr int NW = 2 * (TI + TO) * 4096 > 80 * 1024 ? 8 : 4;
+  const size_t lds = 2 * (size_t)(TI + TO) * 2 * 2 * 64 * 16 + (size_t)m->L1.out_tiles * 32 * 4;
+  static size_t raised = 0;  // more than the 64 KB a launch gets by default
+  if (lds > 65536 && lds > raised) {
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised = lds;
   }
-#undef ML_
+  constexpr int rows = 32 * NW;
+  const dim3 grid((unsigned)((M + rows - 1) / rows)), block(64 * NW);
+  hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
+}
+
+template <int TI>
+int launch_mlp2(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y) {
+  switch (m->L2.out_tiles) {
+    case 1: return launch_mlp2_to<TI, 1>(m, st, x, M, relu_out, y);
+    case 2: return launch_mlp2_to<TI, 2>(m, st, x, M, relu_out, y);
+    case 3: return launch_mlp2_to<TI, 3>(m, st, x, M, relu_out, y);
+    case 4: return launch_mlp2_to<TI, 4>(m, st, x, M, relu_out, y);
+    case 5: return launch_mlp2_to<TI, 5>(m, st, x, M, relu_out, y);
+    case 6: return launch_mlp2_to<TI, 6>(m, st, x, M, relu_out, y);
+    case 7: return launch_mlp2_to<TI, 7>(m, st, x, M, relu_out, y);
+    default: return fail(EBC_ERR_UNSUPPORTED, "mlp2: more than 224 outputs");
+  }
 }
 
 }  // namespace
