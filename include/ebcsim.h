@@ -253,8 +253,8 @@ int ebc_timing(void *handle, int enable);
 int ebc_timing_read(void *handle, int reset, double *avg_ms, int64_t *launches);
 
 /* ---- value-network layers (the consumer of ebc_lookahead's rows) -------------------------------
- * A two-layer block of the reference's mlp() helper (rl/policy/cadrl.py:9-20: Linear + ReLU stacks;
- * rl/policy/sarl.py:13-21 builds mlp1 / mlp2 / attention / mlp3 from it):
+ * A two-layer block of the reference's mlp() helper (rl/policy/cadrl.py:13-21: Linear + ReLU stacks;
+ * rl/policy/sarl.py:25-35 builds mlp1 / mlp2 / attention / mlp3 from it):
  *     y = [relu] (W2 relu(W1 x + b1) + b2),   x [M][K0] -> y [M][O]   (float32, device)
  * on the bf16 matrix cores with every float32 operand split in two bf16 numbers (three products kept):
  * float32-grade results (tests/test_value_net.py: 4e-5 relative; 1.5e-5 on the value of the reference's
