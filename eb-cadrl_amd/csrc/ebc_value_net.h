@@ -38,6 +38,18 @@ __device__ __forceinline__ Frag2 split8(const float (&v)[8]) {
   return f;
 }
 
+// Two things the attention stack of the value network needs beyond a plain two-layer block.
+//   row_bias [M / group_rows][H]: added to the hidden pre-activation of every row of a group (the
+//     pair's mean-state term of attention layer 0, cat([h1, g]) without the concatenation);
+//   final_w [O], final_b: a third layer with one output, y [M] = final_w . relu(out) + final_b,
+//     worked out from the accumulators instead of storing out [M][O].
+struct MlpExtra {
+  const float *row_bias;
+  int group_rows, H;
+  const float *final_w;
+  float final_b;
+};
+
 // Packed layer: A fragments [out tile][in tile][k-step 0/1][hi, lo][lane][8 bf16] and the bias in
 // accumulator order [out tile][lane half][16].
 struct PackedLayer {
@@ -79,7 +91,7 @@ __device__ __forceinline__ void tile_frags(const f32x16 &acc, bool relu, Frag2 (
 // (two waves per SIMD either way: one's conversions run under the other's MFMAs).
 template <int TI, int TO, int NW>
 __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_wg_kernel(const float *X, int M, int K0, PackedLayer L1,
-                                                           PackedLayer L2, int relu_out, float *Y, int O) {
+                                                           PackedLayer L2, int relu_out, float *Y, int O, MlpExtra ex) {
   extern __shared__ uint4 wbuf[];  // [2][PER_U] weights, then the hidden layer's biases
   constexpr int PART = 64;                          // uint4 per fragment half (hi or lo) = 1 KB
   constexpr int PER_U = (TI + TO) * 2 * 2 * PART;   // uint4 per hidden tile: its L1 row block + its L2 column block
@@ -125,11 +137,33 @@ __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_w
   f32x16 out[TO][1];
 #pragma unroll
   for (int t = 0; t < TO; ++t) out[t][0] = bias_tile(L2, t, lane);
+  // the group term of hidden tile u for this lane's row: units 8 g + 4 half + 0..3 of the tile for g = 0..3.
+  // Loaded one tile ahead and BEFORE that tile's weights are staged: loads retire in order, so the wait
+  // for these values at the top of the next iteration waits for nothing that is not needed then anyway.
+  const float *gb = (ex.row_bias && m < M) ? ex.row_bias + (size_t)(m / ex.group_rows) * ex.H : nullptr;
+  auto group_bias = [&](int u, float4 (&v)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int unit = u * 32 + 8 * g + 4 * half;
+      v[g] = make_float4(0, 0, 0, 0);
+      if (gb && unit + 3 < ex.H) v[g] = *reinterpret_cast<const float4 *>(gb + unit);
+      else if (gb) {
+        if (unit < ex.H) v[g].x = gb[unit];
+        if (unit + 1 < ex.H) v[g].y = gb[unit + 1];
+        if (unit + 2 < ex.H) v[g].z = gb[unit + 2];
+      }
+    }
+  };
+  float4 gcur[4], gnext[4];
+  group_bias(0, gcur);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count the asm loads
   __syncthreads();
   for (int u = 0; u < hidden_tiles; ++u) {
     const int buf = u & 1;
-    if (u + 1 < hidden_tiles) stage(u + 1, buf ^ 1);
+    if (u + 1 < hidden_tiles) {
+      group_bias(u + 1, gnext);
+      stage(u + 1, buf ^ 1);
+    }
     const uint4 *w = wbuf + (size_t)buf * PER_U + lane;
     auto frag = [&](int blk, int s) {
       const uint4 h = w[((blk * 2 + s) * 2) * PART], l = w[((blk * 2 + s) * 2 + 1) * PART];
@@ -147,7 +181,8 @@ __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_w
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = hb[q];
-        hC[4 * q] = v.x; hC[4 * q + 1] = v.y; hC[4 * q + 2] = v.z; hC[4 * q + 3] = v.w;
+        hC[4 * q] = v.x + gcur[q].x; hC[4 * q + 1] = v.y + gcur[q].y;
+        hC[4 * q + 2] = v.z + gcur[q].z; hC[4 * q + 3] = v.w + gcur[q].w;
       }
     }
 #pragma unroll
@@ -183,8 +218,23 @@ __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_w
         for (int c = 0; c < C; ++c)
           if (t0 + c < TO) out[t0 + c][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c].hi, hf[s].hi, out[t0 + c][0], 0, 0, 0);
       }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gcur[g] = gnext[g];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile u + 1 has landed ...
     __syncthreads();                                   // ... and everybody's; buffer `buf` is free
+  }
+  if (ex.final_w) {  // third layer with one output: a dot product over the units this lane holds, then the other half's
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TO; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (unit < O) acc += ex.final_w[unit] * fmaxf(out[t][0][r], 0.0f);
+      }
+    acc += __shfl_xor(acc, 32, 64);
+    if (m < M && half == 0) Y[m] = acc + ex.final_b;
+    return;
   }
   if (m < M) {
     const bool vec = (O & 3) == 0;  // registers 4g .. 4g+3 are four consecutive units: one 16-byte store

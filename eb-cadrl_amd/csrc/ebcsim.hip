@@ -798,6 +798,8 @@ float bf16_to_float(uint16_t b) {
 struct Mlp2 {
   int device = 0, K0 = 0, H = 0, O = 0;
   ebc::PackedLayer L1{}, L2{};
+  float *final_w = nullptr;  // optional third layer with one output
+  float final_b = 0.0f;
   std::vector<void *> allocs;
 };
 
@@ -843,7 +845,7 @@ int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool ac
 }
 
 template <int TI, int TO>
-int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y) {
+int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
   // NW waves per workgroup, a 32-row tile each; the weights of one hidden tile twice in LDS
   constexpr int NW = 2 * (TI + TO) * 4096 > 80 * 1024 ? 8 : 4;
   const size_t lds = 2 * (size_t)(TI + TO) * 2 * 2 * 64 * 16 + (size_t)m->L1.out_tiles * 32 * 4;
@@ -854,21 +856,21 @@ int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int rel
   }
   constexpr int rows = 32 * NW;
   const dim3 grid((unsigned)((M + rows - 1) / rows)), block(64 * NW);
-  hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O);
+  hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
 
 template <int TI>
-int launch_mlp2(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y) {
+int launch_mlp2(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
   switch (m->L2.out_tiles) {
-    case 1: return launch_mlp2_to<TI, 1>(m, st, x, M, relu_out, y);
-    case 2: return launch_mlp2_to<TI, 2>(m, st, x, M, relu_out, y);
-    case 3: return launch_mlp2_to<TI, 3>(m, st, x, M, relu_out, y);
-    case 4: return launch_mlp2_to<TI, 4>(m, st, x, M, relu_out, y);
-    case 5: return launch_mlp2_to<TI, 5>(m, st, x, M, relu_out, y);
-    case 6: return launch_mlp2_to<TI, 6>(m, st, x, M, relu_out, y);
-    case 7: return launch_mlp2_to<TI, 7>(m, st, x, M, relu_out, y);
+    case 1: return launch_mlp2_to<TI, 1>(m, st, x, M, relu_out, y, ex);
+    case 2: return launch_mlp2_to<TI, 2>(m, st, x, M, relu_out, y, ex);
+    case 3: return launch_mlp2_to<TI, 3>(m, st, x, M, relu_out, y, ex);
+    case 4: return launch_mlp2_to<TI, 4>(m, st, x, M, relu_out, y, ex);
+    case 5: return launch_mlp2_to<TI, 5>(m, st, x, M, relu_out, y, ex);
+    case 6: return launch_mlp2_to<TI, 6>(m, st, x, M, relu_out, y, ex);
+    case 7: return launch_mlp2_to<TI, 7>(m, st, x, M, relu_out, y, ex);
     default: return fail(EBC_ERR_UNSUPPORTED, "mlp2: more than 224 outputs");
   }
 }
@@ -878,7 +880,7 @@ int launch_mlp2(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_o
 extern "C" {
 
 int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
-                    const float *b2, void **out) {
+                    const float *b2, const float *w3, const float *b3, void **out) {
   if (!w1 || !b1 || !w2 || !b2 || !out) return fail(EBC_ERR_INVALID, "null argument");
   if (K0 <= 0 || H <= 0 || O <= 0 || K0 > 224 || O > 224) return fail(EBC_ERR_UNSUPPORTED, "mlp2 dimensions");
   int count = 0;
@@ -890,6 +892,14 @@ int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const 
   m->device = device_id; m->K0 = K0; m->H = H; m->O = O;
   int rc = pack_layer(m, w1, b1, H, K0, false, &m->L1);
   if (rc == EBC_OK) rc = pack_layer(m, w2, b2, O, H, true, &m->L2);
+  if (rc == EBC_OK && w3) {
+    void *dw = nullptr;
+    if (hipMalloc(&dw, (size_t)O * 4) != hipSuccess || hipMemcpy(dw, w3, (size_t)O * 4, hipMemcpyHostToDevice) != hipSuccess)
+      rc = fail(EBC_ERR_DEVICE, "mlp2: third layer upload failed");
+    if (dw) m->allocs.push_back(dw);
+    m->final_w = (float *)dw;
+    m->final_b = b3 ? b3[0] : 0.0f;
+  }
   if (rc != EBC_OK) {
     for (void *ptr : m->allocs) (void)hipFree(ptr);
     delete m;
@@ -899,20 +909,23 @@ int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const 
   return EBC_OK;
 }
 
-int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_out, float *y) {
+int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
+                     int group_rows, float *y) {
   Mlp2 *m = (Mlp2 *)mlp;
   if (!m || !x || !y || M < 0) return fail(EBC_ERR_INVALID, "mlp2 forward arguments");
+  if (row_bias && group_rows <= 0) return fail(EBC_ERR_INVALID, "mlp2: group_rows");
   if (M == 0) return EBC_OK;
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = (hipStream_t)stream;
+  const ebc::MlpExtra ex = {row_bias, group_rows, m->H, m->final_w, m->final_b};
   switch (m->L1.in_tiles) {
-    case 1: return launch_mlp2<1>(m, st, x, M, relu_out, y);
-    case 2: return launch_mlp2<2>(m, st, x, M, relu_out, y);
-    case 3: return launch_mlp2<3>(m, st, x, M, relu_out, y);
-    case 4: return launch_mlp2<4>(m, st, x, M, relu_out, y);
-    case 5: return launch_mlp2<5>(m, st, x, M, relu_out, y);
-    case 6: return launch_mlp2<6>(m, st, x, M, relu_out, y);
-    default: return launch_mlp2<7>(m, st, x, M, relu_out, y);
+    case 1: return launch_mlp2<1>(m, st, x, M, relu_out, y, ex);
+    case 2: return launch_mlp2<2>(m, st, x, M, relu_out, y, ex);
+    case 3: return launch_mlp2<3>(m, st, x, M, relu_out, y, ex);
+    case 4: return launch_mlp2<4>(m, st, x, M, relu_out, y, ex);
+    case 5: return launch_mlp2<5>(m, st, x, M, relu_out, y, ex);
+    case 6: return launch_mlp2<6>(m, st, x, M, relu_out, y, ex);
+    default: return launch_mlp2<7>(m, st, x, M, relu_out, y, ex);
   }
 }
 

@@ -31,8 +31,9 @@ SYMBOLS = {
     "ebc_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ebc_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ebc_mlp2_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                  C.c_void_p, C.POINTER(C.c_void_p)]),
-    "ebc_mlp2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "ebc_mlp2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p]),
     "ebc_mlp2_destroy": (C.c_int, [C.c_void_p]),
 }
 

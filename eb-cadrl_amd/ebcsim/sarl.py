@@ -31,24 +31,36 @@ def _mlp(x, layers, last_relu):
 class _NativeMlp2(object):
     """A two-layer block on the bf16 matrix cores with split operands (libebcsim ebc_mlp2_*)."""
 
-    def __init__(self, layers, device_index):
+    def __init__(self, layers, device_index, final=None):
+        """layers: [(w1, b1), (w2, b2)]; final: optional (w3 [1, O], b3 [1]) third layer with one output."""
         import ctypes as C
         from . import _capi
         (w1, b1), (w2, b2) = layers
         self._L, self._C = _capi.lib(), C
         self.K0, self.H, self.O = int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])
         host = [t.detach().to("cpu", torch.float32).contiguous().numpy() for t in (w1, b1, w2, b2)]
+        self.has_final = final is not None
+        if final is not None:
+            host += [final[0].detach().to("cpu", torch.float32).reshape(-1).contiguous().numpy(),
+                     final[1].detach().to("cpu", torch.float32).reshape(-1).contiguous().numpy()]
         self._h = C.c_void_p()
         _capi.check(self._L.ebc_mlp2_create(int(device_index), self.K0, self.H, self.O, host[0].ctypes.data,
                                             host[1].ctypes.data, host[2].ctypes.data, host[3].ctypes.data,
+                                            host[4].ctypes.data if final is not None else None,
+                                            host[5].ctypes.data if final is not None else None,
                                             C.byref(self._h)))
 
-    def __call__(self, x, relu_out):
+    def __call__(self, x, relu_out, row_bias=None, group_rows=0):
         from . import _capi
         x = x.contiguous()
-        y = torch.empty((x.shape[0], self.O), dtype=torch.float32, device=x.device)
+        shape = (x.shape[0],) if self.has_final else (x.shape[0], self.O)
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+        if row_bias is not None:
+            row_bias = row_bias.contiguous()
         _capi.check(self._L.ebc_mlp2_forward(self._h, torch.cuda.current_stream(x.device).cuda_stream,
-                                             x.data_ptr(), int(x.shape[0]), int(bool(relu_out)), y.data_ptr()))
+                                             x.data_ptr(), int(x.shape[0]), int(bool(relu_out)),
+                                             None if row_bias is None else row_bias.data_ptr(), int(group_rows),
+                                             y.data_ptr()))
         return y
 
     def __del__(self):
@@ -88,11 +100,17 @@ class SarlValueNet(object):
         if getattr(self, "_native", ()) is None:  # nets assembled by hand (training) carry no blocks
             ok = (self.device.type == "cuda" and self.dtype == torch.float32 and len(self.mlp1) == 2
                   and len(self.mlp2) == 2 and len(self.attention) == 3 and self.with_global_state)
-            stacks = (self.mlp1, self.mlp2, self.attention[1:])
-            if ok and all(st[0][0].shape[1] <= 224 and st[1][0].shape[0] <= 224 for st in stacks):
+            H = self.mlp1[-1][0].shape[0] if ok else 0
+            # attention = layer 0 on cat([h1, g]) | layer 1 | layer 2 (one output): the h1 half of layer 0
+            # and layer 1 form the block, g's half enters as a per-pair term, layer 2 is the block's tail
+            att = ok and [(self.attention[0][0][:, :H], torch.zeros_like(self.attention[0][1])), self.attention[1]]
+            stacks = (self.mlp1, self.mlp2, att) if ok else ()
+            if ok and self.attention[2][0].shape[0] == 1 and all(
+                    st[0][0].shape[1] <= 224 and st[1][0].shape[0] <= 224 for st in stacks):
                 idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
                 try:
-                    self._native = tuple(_NativeMlp2(st, idx) for st in stacks)
+                    self._native = (_NativeMlp2(self.mlp1, idx), _NativeMlp2(self.mlp2, idx),
+                                    _NativeMlp2(att, idx, final=self.attention[2]))
                 except Exception:  # an unsupported shape: stay on the torch path
                     self._native = ()
             else:
@@ -135,11 +153,11 @@ class SarlValueNet(object):
             H = h1.shape[1]
             w0, b0 = self.attention[0]
             gterm = torch.nn.functional.linear(g, w0[:, H:], b0)  # [B, A1]
-            a1 = torch.nn.functional.linear(h1, w0[:, :H]).view(B, R, -1)
-            a1 = torch.relu(a1 + gterm[:, None, :]).view(B * R, -1)
             if nat is not None:
-                scores = nat[2](a1, False).view(B, R)
+                scores = nat[2](h1, False, row_bias=gterm, group_rows=R).view(B, R)
             else:
+                a1 = torch.nn.functional.linear(h1, w0[:, :H]).view(B, R, -1)
+                a1 = torch.relu(a1 + gterm[:, None, :]).view(B * R, -1)
                 scores = _mlp(a1, self.attention[1:], False).view(B, R)
         else:
             scores = _mlp(h1, self.attention, False).view(B, R)

@@ -259,11 +259,17 @@ int ebc_timing_read(void *handle, int reset, double *avg_ms, int64_t *launches);
  * on the bf16 matrix cores with every float32 operand split in two bf16 numbers (three products kept):
  * float32-grade results (tests/test_value_net.py: 4e-5 relative; 1.5e-5 on the value of the reference's
  * decision runs) at several times the float32 GEMM rate, the hidden layer never leaving the registers.
- * w1 [H][K0], b1 [H], w2 [O][H], b2 [O]: host pointers, torch.nn.Linear layout.  K0, O <= 224. */
+ * w1 [H][K0], b1 [H], w2 [O][H], b2 [O]: host pointers, torch.nn.Linear layout.  K0, O <= 224.
+ * Optional third layer with ONE output (the attention score): w3 [O], b3 [1] (NULL = none); forward
+ * then writes y [M] = w3 . relu(W2 ... + b2) + b3 and the [M][O] activations never reach memory. */
 int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
-                    const float *b2, void **mlp_out);
-/* x, y: device pointers; stream: hipStream_t (NULL = the null stream); relu_out: ReLU on y. */
-int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_out, float *y);
+                    const float *b2, const float *w3, const float *b3, void **mlp_out);
+/* x, y: device pointers; stream: hipStream_t (NULL = the null stream); relu_out: ReLU on y.
+ * row_bias (device, NULL = none) [M / group_rows][H]: added to the hidden pre-activation of every row of
+ * a group of group_rows consecutive rows — ValueNetwork's attention input cat([h, mean(h)]) (sarl.py:56-62)
+ * without the concatenation: the mean's half of the first attention layer acts once per pair. */
+int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
+                     int group_rows, float *y);
 int ebc_mlp2_destroy(void *mlp);
 
 #ifdef __cplusplus

@@ -27,11 +27,11 @@ def test_mlp2_split_bf16_matches_float32(K0, H, O, M, relu_out):
     x = (rs.randn(M, K0) * 2).astype(np.float32)
     h = C.c_void_p()
     _capi.check(L.ebc_mlp2_create(0, K0, H, O, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data,
-                                  C.byref(h)))
+                                  None, None, C.byref(h)))
     xd = torch.from_numpy(x).cuda()
     yd = torch.zeros((M, O), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()
-    _capi.check(L.ebc_mlp2_forward(h, None, xd.data_ptr(), M, relu_out, yd.data_ptr()))
+    _capi.check(L.ebc_mlp2_forward(h, None, xd.data_ptr(), M, relu_out, None, 0, yd.data_ptr()))
     torch.cuda.synchronize()
     ref = np.maximum(x.astype(np.float64) @ w1.T.astype(np.float64) + b1, 0) @ w2.T.astype(np.float64) + b2
     if relu_out:
@@ -45,4 +45,36 @@ def test_mlp2_split_bf16_matches_float32(K0, H, O, M, relu_out):
     scale = np.abs(ref).max()
     # three bf16 products per f32 product: relative error per term ~2^-16; float32 itself is ~1e-6 here
     assert err <= 4e-5 * max(scale, 1.0), (err, err32, scale)
+    _capi.check(L.ebc_mlp2_destroy(h))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K0,H,O,R,B", [(200, 200, 200, 18, 777), (100, 100, 100, 5, 1031), (40, 70, 33, 7, 64)])
+def test_mlp2_attention_form(K0, H, O, R, B):
+    """The attention stack's form: a per-group term added to the hidden pre-activation (the pair's mean
+    state through its half of layer 0) and a third layer with one output taken from the accumulators."""
+    import torch
+    from ebcsim import _capi
+    L = _lib()
+    rs = np.random.RandomState(K0 + R)
+    M = B * R
+    w1 = (rs.randn(H, K0) / np.sqrt(K0)).astype(np.float32); b1 = (rs.randn(H) * 0.1).astype(np.float32)
+    w2 = (rs.randn(O, H) / np.sqrt(H)).astype(np.float32); b2 = (rs.randn(O) * 0.1).astype(np.float32)
+    w3 = (rs.randn(O) / np.sqrt(O)).astype(np.float32); b3 = np.array([0.3], np.float32)
+    x = rs.randn(M, K0).astype(np.float32)
+    g = rs.randn(B, H).astype(np.float32)
+    h = C.c_void_p()
+    _capi.check(L.ebc_mlp2_create(0, K0, H, O, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data,
+                                  w3.ctypes.data, b3.ctypes.data, C.byref(h)))
+    xd, gd = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda()
+    yd = torch.zeros(M, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    _capi.check(L.ebc_mlp2_forward(h, None, xd.data_ptr(), M, 0, gd.data_ptr(), R, yd.data_ptr()))
+    torch.cuda.synchronize()
+    x64, g64 = x.astype(np.float64), np.repeat(g.astype(np.float64), R, axis=0)
+    a1 = np.maximum(x64 @ w1.T.astype(np.float64) + b1 + g64, 0)
+    a2 = np.maximum(a1 @ w2.T.astype(np.float64) + b2, 0)
+    ref = a2 @ w3.astype(np.float64) + b3[0]
+    err = np.abs(yd.cpu().numpy() - ref).max()
+    assert err <= 4e-5 * max(np.abs(ref).max(), 1.0), err
     _capi.check(L.ebc_mlp2_destroy(h))

@@ -21,13 +21,13 @@ def main():
         w1 = (rs.randn(H, K0) / np.sqrt(K0)).astype(np.float32); b1 = rs.randn(H).astype(np.float32)
         w2 = (rs.randn(O, H) / np.sqrt(H)).astype(np.float32); b2 = rs.randn(O).astype(np.float32)
         h = C.c_void_p()
-        _capi.check(L.ebc_mlp2_create(0, K0, H, O, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data, C.byref(h)))
+        _capi.check(L.ebc_mlp2_create(0, K0, H, O, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data, None, None, C.byref(h)))
         x = torch.randn(M, K0, device="cuda"); y = torch.empty(M, O, device="cuda")
         tw1, tb1, tw2, tb2 = (torch.from_numpy(a).cuda() for a in (w1, b1, w2, b2))
         st = torch.cuda.current_stream().cuda_stream
 
         def native():
-            _capi.check(L.ebc_mlp2_forward(h, st, x.data_ptr(), M, 1, y.data_ptr()))
+            _capi.check(L.ebc_mlp2_forward(h, st, x.data_ptr(), M, 1, None, 0, y.data_ptr()))
 
         def ref():
             return torch._addmm_activation(tb2, torch._addmm_activation(tb1, x, tw1.t()), tw2.t())
