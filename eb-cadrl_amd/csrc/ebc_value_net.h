@@ -87,10 +87,11 @@ __device__ __forceinline__ void tile_frags(const f32x16 &acc, bool relu, Frag2 (
 // between — and double-buffered: while the waves work on hidden tile u from one buffer, tile u + 1
 // arrives in the other.  (With the weights coming from L2 per wave and per k-step a wave spent nine
 // tenths of its time waiting for them.)
-// NW waves per workgroup: 4 when two workgroups' weight buffers fit a CU's LDS side by side, else 8
-// (two waves per SIMD either way: one's conversions run under the other's MFMAs).
-template <int TI, int TO, int NW>
-__global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_wg_kernel(const float *X, int M, int K0, PackedLayer L1,
+// NW waves per workgroup: 8 (two per SIMD sharing one copy of the weights) when the tiles fit 256
+// registers and the double buffer is too big for two workgroups per CU; else 4 (two workgroups per CU when
+// LDS allows, one wave per SIMD with up to 512 registers when the tiles need them).
+template <int TI, int TO, int NW, bool GROUP>
+__global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) void mlp2_split_wg_kernel(const float *X, int M, int K0, PackedLayer L1,
                                                            PackedLayer L2, int relu_out, float *Y, int O, MlpExtra ex) {
   extern __shared__ uint4 wbuf[];  // [2][PER_U] weights, then the hidden layer's biases
   constexpr int PART = 64;                          // uint4 per fragment half (hi or lo) = 1 KB
@@ -137,10 +138,8 @@ __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_w
   f32x16 out[TO][1];
 #pragma unroll
   for (int t = 0; t < TO; ++t) out[t][0] = bias_tile(L2, t, lane);
-  // the group term of hidden tile u for this lane's row: units 8 g + 4 half + 0..3 of the tile for g = 0..3.
-  // Loaded one tile ahead and BEFORE that tile's weights are staged: loads retire in order, so the wait
-  // for these values at the top of the next iteration waits for nothing that is not needed then anyway.
-  const float *gb = (ex.row_bias && m < M) ? ex.row_bias + (size_t)(m / ex.group_rows) * ex.H : nullptr;
+  // the group term of hidden tile u for this lane's row: units 8 g + 4 half + 0..3 of the tile for g = 0..3
+  const float *gb = (GROUP && m < M) ? ex.row_bias + (size_t)(m / ex.group_rows) * ex.H : nullptr;
   auto group_bias = [&](int u, float4 (&v)[4]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -154,16 +153,15 @@ __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_w
       }
     }
   };
-  float4 gcur[4], gnext[4];
-  group_bias(0, gcur);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count the asm loads
   __syncthreads();
   for (int u = 0; u < hidden_tiles; ++u) {
     const int buf = u & 1;
-    if (u + 1 < hidden_tiles) {
-      group_bias(u + 1, gnext);
-      stage(u + 1, buf ^ 1);
-    }
+    // this tile's group term first (its wait, after the first batch of MFMAs below, then also waits for
+    // the staging issued behind it — by then that has had those MFMAs' time), then the next tile's weights
+    float4 gcur[4];
+    if (GROUP) group_bias(u, gcur);
+    if (u + 1 < hidden_tiles) stage(u + 1, buf ^ 1);
     const uint4 *w = wbuf + (size_t)buf * PER_U + lane;
     auto frag = [&](int blk, int s) {
       const uint4 h = w[((blk * 2 + s) * 2) * PART], l = w[((blk * 2 + s) * 2 + 1) * PART];
@@ -173,16 +171,15 @@ __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_w
       return f;
     };
     // A dependent MFMA waits for the one before it (64 cycles against a 32-cycle issue interval), so
-    // consecutive MFMAs go to different accumulators: the hidden tile collects its three kinds of
-    // terms in three accumulators (summed small-first at the end), the output tiles take turns.
-    f32x16 hA = {}, hB = {}, hC;
+    // consecutive MFMAs go to different accumulators: the hidden tile alternates between two (summed at
+    // the end), the output tiles take turns.
+    f32x16 hacc[2] = {{}, {}};
     {
       const float4 *hb = reinterpret_cast<const float4 *>(hbias + (u * 2 + half) * 16);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = hb[q];
-        hC[4 * q] = v.x + gcur[q].x; hC[4 * q + 1] = v.y + gcur[q].y;
-        hC[4 * q + 2] = v.z + gcur[q].z; hC[4 * q + 3] = v.w + gcur[q].w;
+        hacc[0][4 * q] = v.x; hacc[0][4 * q + 1] = v.y; hacc[0][4 * q + 2] = v.z; hacc[0][4 * q + 3] = v.w;
       }
     }
 #pragma unroll
@@ -190,13 +187,21 @@ __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_w
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const Frag2 wf = frag(i, s);
-        hA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.lo, x[i][s][0].hi, hA, 0, 0, 0);
-        hB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].lo, hB, 0, 0, 0);
-        hC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].hi, hC, 0, 0, 0);
+        constexpr int first = 1;  // three MFMAs per step: 1 0 1 | 0 1 0 | ... never the same accumulator twice in a row
+        const int p = ((i * 2 + s) & 1) ? 1 - first : first;
+        hacc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.lo, x[i][s][0].hi, hacc[p], 0, 0, 0);
+        hacc[1 - p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].lo, hacc[1 - p], 0, 0, 0);
+        hacc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].hi, hacc[p], 0, 0, 0);
       }
     f32x16 hid;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hid[r] = (hA[r] + hB[r]) + hC[r];
+    for (int r = 0; r < 16; ++r) hid[r] = hacc[0][r] + hacc[1][r];
+    if (GROUP) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        hid[4 * q] += gcur[q].x; hid[4 * q + 1] += gcur[q].y; hid[4 * q + 2] += gcur[q].z; hid[4 * q + 3] += gcur[q].w;
+      }
+    }
     Frag2 hf[2];
     tile_frags(hid, true, hf);
 #pragma unroll
@@ -218,8 +223,6 @@ __global__ __launch_bounds__(64 * NW, (TI + TO <= 11 ? 2 : 1)) void mlp2_split_w
         for (int c = 0; c < C; ++c)
           if (t0 + c < TO) out[t0 + c][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c].hi, hf[s].hi, out[t0 + c][0], 0, 0, 0);
       }
-#pragma unroll
-    for (int g = 0; g < 4; ++g) gcur[g] = gnext[g];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile u + 1 has landed ...
     __syncthreads();                                   // ... and everybody's; buffer `buf` is free
   }

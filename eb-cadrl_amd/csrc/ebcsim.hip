@@ -847,16 +847,21 @@ int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool ac
 template <int TI, int TO>
 int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
   // NW waves per workgroup, a 32-row tile each; the weights of one hidden tile twice in LDS
-  constexpr int NW = 2 * (TI + TO) * 4096 > 80 * 1024 ? 8 : 4;
+  constexpr bool fits256 = (TI + TO) * 16 + 64 <= 256;  // fragments, accumulators, working set (as the kernel's launch bounds)
+  constexpr int NW = (fits256 && 2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4;
   const size_t lds = 2 * (size_t)(TI + TO) * 2 * 2 * 64 * 16 + (size_t)m->L1.out_tiles * 32 * 4;
   static size_t raised = 0;  // more than the 64 KB a launch gets by default
   if (lds > 65536 && lds > raised) {
-    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = lds;
   }
   constexpr int rows = 32 * NW;
   const dim3 grid((unsigned)((M + rows - 1) / rows)), block(64 * NW);
-  hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
+  if (ex.row_bias)
+    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, true>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
+  else
+    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, false>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
