@@ -60,31 +60,73 @@ def build_batch(workload, envs, rank):
     return params, ebc_scene.SceneBatch.from_scenes(scenes)
 
 
-def cpu_baseline(params, batch, seconds_target=12.0):
-    """The CPU oracle (scalar C restatement, 1 thread) on a bounded sample of the same workload."""
+def host_cores(cap=16):
+    """Threads for the all-cores CPU baseline: this process's CPU share — its affinity mask, cut
+    to the cgroup quota when one is set, and to `cap` (the CPU share of a one-GPU box: a mask of
+    256 logical CPUs there does not mean 256 cores are this job's)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(params, batch, seconds_target=7.0):
+    """The CPU oracle (scalar C restatement) on a bounded sample of the same workload: one
+    thread, then the env loop spread over every core this process may use (OpenMP static split;
+    envs are independent).  `value` is the all-cores rate, `cores` the threads it used."""
     from ebcsim import _abi, scene as ebc_scene
     from oracle import oracle
-    n = min(256, batch.n)
-    sub = ebc_scene.SceneBatch(n, batch.N, batch.S, *[
-        None if getattr(batch, k) is None else getattr(batch, k)[:n] for k in (
-            "n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
-            "n_static", "spx", "spy", "sradius", "grid", "robot")])
-    env = oracle.OracleEnv(params, n, batch.N, batch.S)
-    env.reset(sub)
+    cores = host_cores()
     flags = _abi.FLAG_AUTO_RESET
-    env.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=flags)
-    steps, t0 = 0, time.perf_counter()
-    while True:
-        for _ in range(10):
-            env.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=flags)
-        steps += 10
-        dt = time.perf_counter() - t0
-        if dt >= seconds_target or steps >= 100000:
-            break
-    humans = int(sub.n_humans.sum())
-    return {"value": humans * steps / dt, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-            "sample": "%d envs x %d humans x %d steps of the same workload, oracle/ebc_oracle.c, "
-                      "1 thread, %.1f s" % (n, batch.N, steps, dt)}
+    kw = dict(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=flags)
+
+    def sample(n, threads, chunk):
+        sub = ebc_scene.SceneBatch(n, batch.N, batch.S, *[
+            None if getattr(batch, k) is None else getattr(batch, k)[:n] for k in (
+                "n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
+                "n_static", "spx", "spy", "sradius", "grid", "robot")])
+        env = oracle.OracleEnv(params, n, batch.N, batch.S)
+        env.reset(sub)
+        oracle.set_threads(threads)
+        try:
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 1.0:  # thread team, page faults, clocks
+                env.step(**kw)
+            steps, t0 = 0, time.perf_counter()
+            while True:
+                for _ in range(chunk):
+                    env.step(**kw)
+                steps += chunk
+                dt = time.perf_counter() - t0
+                if dt >= seconds_target or steps >= 100000:
+                    break
+        finally:
+            oracle.set_threads(1)
+        return int(sub.n_humans.sum()) * steps / dt, steps, dt
+
+    n1 = min(256, batch.n)
+    v1, s1, t1 = sample(n1, 1, 10)
+    out = {"value": v1, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+           "sample": "%d envs x %d humans x %d steps of the same workload, oracle/ebc_oracle.c, "
+                     "1 thread, %.1f s" % (n1, batch.N, s1, t1)}
+    if cores > 1:
+        nc = batch.n  # the whole batch: every thread gets a contiguous env slice
+        vc, sc, tc = sample(nc, cores, 2)
+        out = {"value": vc, "unit": "agent-steps/s", "cores": cores, "kind": "port",
+               "sample": "%d envs x %d humans x %d steps of the same workload, oracle/ebc_oracle.c, "
+                         "%d OpenMP threads over envs, %.1f s" % (nc, batch.N, sc, cores, tc),
+               "single_thread": {"value": v1, "sample": out["sample"]}}
+    return out
 
 
 def main():
@@ -170,7 +212,11 @@ def main():
     if rank == 0:
         S_mean = float(batch.n_static.mean()) if batch.S else 0.0
         bytes_launch = algorithmic_bytes_per_env_step(batch.N, S_mean, env.T) * E
-        achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # one launch per step: the launch's average duration over the timed region = HIP events
+        # around the region / K (rocprofv3 --kernel-trace --stats of this command agrees, profiles/);
+        # kernel_ms = events around every single launch in a separate pass (they add ~2 us each)
+        launch_ms = stream_ms / args.steps
+        achieved = bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
         traffic = None  # PMC-measured HBM bytes per step, from the committed profile of this workload
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tpath) and world == 1:
@@ -190,8 +236,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "orca_step_kernel (the one launch of a step)",
-                         "kernel_ms": kernel_ms,
-                         "stream_ms_per_step": stream_ms / args.steps,
+                         "launch_ms": launch_ms, "kernel_ms_event_pair": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -489,11 +489,15 @@ __device__ __forceinline__ void robot_advance(const EbcParams &p, double *rb, do
 // `epoch` != 0 (fused ORCA step): the leader publishes the robot's next state in s.robot_n as soon
 // as the action is known — the ROWS role builds the observation frame from it long before the
 // collision / reward work below is done.
+struct EnvScratch {  // LDS of one service_env wave
+  double cand[3][EBC_WAVE];  // per collision class: this lane's distance, if it counts
+  double ract[EBC_WAVE][2];  // the envs' robot actions
+};
 __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s, const StepIO &io,
                                            const LaneMap &m, const HumanRegs &h, double rb[9],
-                                           double gtime, int lane, unsigned epoch = 0) {
-  __shared__ double sh_cand[3][EBC_WAVE];  // per collision class: this lane's distance, if it counts
-  __shared__ double sh_ract[EBC_WAVE][2];
+                                           double gtime, int lane, EnvScratch &X, unsigned epoch = 0) {
+  double (&sh_cand)[3][EBC_WAVE] = X.cand;
+  double (&sh_ract)[EBC_WAVE][2] = X.ract;
   const double dt = p.time_step;
   int grid_slot = (m.leader && s.pool.grid) ? s.grid_scene[m.ee] : 0;
   pin(grid_slot);
@@ -752,6 +756,7 @@ __global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState
   const WaveTrace wt(1);
   const int lane = threadIdx.x;
   __shared__ ArgBlock args;
+  __shared__ EnvScratch env_scratch;
   __shared__ double sh_rbn[EBC_WAVE][9];
   stage_args(&args.p, p_in, lane);
   stage_args(&args.s, s_in, lane);
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState
   pin_loads(h, pre, rb, gtime);  // every load of the step is back before its first store
   pin(ax);
   pin(ay);
-  int done_flag = service_env(p, s, io, m, h, rb, gtime, lane);
+  int done_flag = service_env(p, s, io, m, h, rb, gtime, lane, env_scratch);
   if (m.leader) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) sh_rbn[m.el][c] = rb[c];
@@ -817,10 +822,15 @@ struct StepGrid {
 };
 
 #define EBC_RBN_ENVS 16  // envs per STATE wave whose restart robot is parked in LDS (more: late loads)
-struct RoleLds {
+struct RoleLds {  // after the arguments, what the role of the wave needs
   ArgBlock args;
-  double restart_robot[EBC_RBN_ENVS][9];  // STATE
+  union {
+    double restart_robot[EBC_RBN_ENVS][9];            // STATE
+    EnvScratch env;                                   // ENV
+    __attribute__((aligned(16))) float rows[EBC_WAVE * 17 + 4];  // ROWS: the wave's rotated rows on their way out
+  };
 };
+static_assert(offsetof(RoleLds, rows) % 16 == 0, "staged rows are read back as 16-byte vectors");
 
 // ---- ENV
 __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in,
@@ -843,7 +853,7 @@ __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &
 #pragma unroll
   for (int q = 0; q < 9; ++q) pin(rb[q]);
   EBC_MARK(0);
-  const int done = service_env(p, s, io, m, h, rb, gtime, lane, epoch);
+  const int done = service_env(p, s, io, m, h, rb, gtime, lane, L.env, epoch);
   if (m.leader) mailbox_put(done_box, 1u + (unsigned)done);
 }
 
@@ -904,6 +914,9 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
   RotFrame f = {};
   int n = env_ok ? s.n_humans[ee] : 0;
   int ns = (env_ok && S) ? s.n_static[ee] : 0;
+  // where this wave's rotated rows start in the output, and that address's offset in a 16-byte vector
+  float *stage_out = io.obs_rotated ? io.obs_rotated + (size_t)block * epw * R * T : nullptr;
+  const int stage_mis = (int)(((size_t)stage_out >> 2) & 3);
   for (int slot = first; slot < R; slot += stride) {
     const bool human = slot < N;
     const size_t k = ee * N + (human ? slot : 0), q = ee * (size_t)(S ? S : 1) + (human ? 0 : slot - N);
@@ -956,11 +969,38 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
         }
         // streaming stores: nobody on the device reads the rows, and what is not left dirty in the
         // L2s does not have to be written back before the next launch may start (-0.2 us per step)
-        float *o = io.obs_rotated + (ee * R + row) * T;
+        if (R <= EBC_WAVE) {  // the wave's rows are one contiguous run of the output: leave through LDS
+          float *st = L.rows + stage_mis + (el * R + row) * T;
 #pragma unroll
-        for (int c = 0; c < T; ++c) __builtin_nontemporal_store(out[c], o + c);
+          for (int c = 0; c < T; ++c) st[c] = out[c];
+        } else {
+          float *o = io.obs_rotated + (ee * R + row) * T;
+#pragma unroll
+          for (int c = 0; c < T; ++c) __builtin_nontemporal_store(out[c], o + c);
+        }
       }
     }
+  }
+  // A lane's row is T floats 4 T bytes apart from its neighbour's: stored from the registers that is T
+  // wave instructions of scattered 4-byte writes, and the CU's memory pipeline is what the STATE waves
+  // next to this one are waiting on.  Staged, the wave's envs x R rows x T floats leave as 16-byte
+  // vectors of consecutive addresses (LDS index = output index mod 4, so both sides stay aligned).
+  if (R <= EBC_WAVE && stage_out) {
+    wave_sync();
+    const int nenv = s.E - (int)(block * epw) < (int)epw ? s.E - (int)(block * epw) : (int)epw;
+    const int total = nenv * R * T;
+    int lead = (4 - stage_mis) & 3;
+    lead = lead < total ? lead : total;
+    const int nvec = (total - lead) >> 2;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    for (int q = lane; q < nvec; q += EBC_WAVE) {
+      const v4f v = *reinterpret_cast<const v4f *>(L.rows + stage_mis + lead + 4 * q);
+      __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(stage_out + lead + 4 * q));
+    }
+    const int tail = lead + 4 * nvec;  // < 4 floats before the first aligned vector, < 4 after the last
+    if (lane < lead) __builtin_nontemporal_store(L.rows[stage_mis + lane], stage_out + lane);
+    if (lane >= 4 && lane - 4 < total - tail)
+      __builtin_nontemporal_store(L.rows[stage_mis + tail + lane - 4], stage_out + tail + lane - 4);
   }
 }
 
@@ -1056,15 +1096,17 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
       const double dx = h.gx - h.px, dy = h.gy - h.py;
       const double dist = norm2(dx, dy);
       if (h.arrival == 0 && dist < h.rad) h.arrival = tnew;
+      float prefx, prefy;
+      orca_pref_from(dx, dy, dist, prefx, prefy);
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const v4f t0 = {(float)h.px, (float)h.py, (float)ax, (float)ay}, t1 = {tile_rad, tile_max, prefx, prefy};
       s.px[m.k] = h.px;
       s.py[m.k] = h.py;
       s.vx[m.k] = ax;
       s.vy[m.k] = ay;
       s.arrival[m.k] = h.arrival;
-      float prefx, prefy;
-      orca_pref_from(dx, dy, dist, prefx, prefy);
-      tile[0] = make_float4((float)h.px, (float)h.py, (float)ax, (float)ay);
-      tile[1] = make_float4(tile_rad, tile_max, prefx, prefy);
+      *reinterpret_cast<v4f *>(tile) = t0;
+      *reinterpret_cast<v4f *>(tile + 1) = t1;
     }
     if (m.leader) s.time[m.ee] = tnew;  // the robot's next state is in robot_n already (ENV)
   } else {

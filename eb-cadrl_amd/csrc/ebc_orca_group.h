@@ -289,10 +289,20 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
   if (lineFail < nn) {
     EBC_COUNT(1);
     float distance = 0.0f;
-    for (int i = lineFail; i < nn; ++i) {
+    // The serial loop walks i = lineFail .. nn - 1 and acts only on lines the current result
+    // violates by more than `distance`; result and distance change only there.  So the next line
+    // it acts on is the first such line at or after `cur`: every lane tests its own line, one
+    // ballot finds it.  A wave then runs the body max-over-its-humans times, not once per index at
+    // which any of its humans (neighbours in one crowded env) happens to be violated.
+    int cur = lineFail;
+    while (true) {
+      const bool far = j >= cur && j < nn && det2(own.dx, own.dy, own.px - rx, own.py - ry) > distance;
+      const unsigned fm = group_ballot<GS>(far, group);
+      if (fm == 0) break;
+      const int i = __ffs(fm) - 1;
+      cur = i + 1;
       const float4 qi = lines_lds[i];
       const Line4 li{qi.x, qi.y, qi.z, qi.w};
-      if (!(det2(li.dx, li.dy, li.px - rx, li.py - ry) > distance)) continue;
       EBC_COUNT(2);
       // projected lines of items < i, compacted in item order (the serial push_back order)
       bool keep = false;

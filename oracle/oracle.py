@@ -61,8 +61,16 @@ def lib():
         L.orc_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lookahead.restype = i
         L.orc_lookahead.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_threads.restype = i
+        L.orc_set_threads.argtypes = [i]
         _LIB = L
     return _LIB
+
+
+def set_threads(n):
+    """Threads orc_step spreads its envs over (1 = the scalar port, the default); returns the
+    value in effect.  Only bench.py's all-cores CPU baseline raises it."""
+    return int(lib().orc_set_threads(int(n)))
 
 
 class OrcState(C.Structure):

@@ -232,3 +232,33 @@ def test_scene_pool_semantics_cpu():
                         flags=_abi.FLAG_AUTO_RESET)
         if out["done"].all():
             np.testing.assert_array_equal(env2.get_state()["px"], b.px)
+
+
+def test_threaded_oracle_equals_scalar():
+    """bench.py's all-cores CPU baseline splits orc_step's env loop over OpenMP threads: same
+    results as the one-thread port, every output and the state, through restarts."""
+    import configparser
+    pkg = os.path.join(os.path.dirname(GOLDEN), "..", "eb-cadrl_amd", "configs")
+    cfg, pol = configparser.RawConfigParser(), configparser.RawConfigParser()
+    cfg.read(os.path.join(pkg, "bench_metric.config"))
+    pol.read(os.path.join(pkg, "policy_agent_type.config"))
+    params = ebc_config.params_from_config(cfg, pol)
+    sc = ebc_scene.SceneConfig.from_config(cfg)
+    batch = ebc_scene.SceneBatch.from_scenes([ebc_scene.generate_scene(sc, 2000 + e) for e in range(24)])
+    kw = dict(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=_abi.FLAG_AUTO_RESET)
+    runs = []
+    for threads in (1, 3):
+        env = oracle.OracleEnv(params, batch.n, batch.N, batch.S)
+        env.reset(batch)
+        assert oracle.set_threads(threads) == threads
+        try:
+            outs = [env.step(**kw) for _ in range(80)]
+        finally:
+            oracle.set_threads(1)
+        runs.append((outs, {k: v.copy() for k, v in env.a.items()}))
+    assert any(o["done"].any() for o in runs[0][0])  # restarts happened
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for k in a:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+    for k in runs[0][1]:
+        assert np.array_equal(runs[0][1][k], runs[1][1][k], equal_nan=True), k
