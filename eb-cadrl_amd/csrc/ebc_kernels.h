@@ -827,10 +827,8 @@ struct RoleLds {  // after the arguments, what the role of the wave needs
   union {
     double restart_robot[EBC_RBN_ENVS][9];            // STATE
     EnvScratch env;                                   // ENV
-    __attribute__((aligned(16))) float rows[EBC_WAVE * 17 + 4];  // ROWS: the wave's rotated rows on their way out
   };
 };
-static_assert(offsetof(RoleLds, rows) % 16 == 0, "staged rows are read back as 16-byte vectors");
 
 // ---- ENV
 __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in,
@@ -914,9 +912,6 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
   RotFrame f = {};
   int n = env_ok ? s.n_humans[ee] : 0;
   int ns = (env_ok && S) ? s.n_static[ee] : 0;
-  // where this wave's rotated rows start in the output, and that address's offset in a 16-byte vector
-  float *stage_out = io.obs_rotated ? io.obs_rotated + (size_t)block * epw * R * T : nullptr;
-  const int stage_mis = (int)(((size_t)stage_out >> 2) & 3);
   for (int slot = first; slot < R; slot += stride) {
     const bool human = slot < N;
     const size_t k = ee * N + (human ? slot : 0), q = ee * (size_t)(S ? S : 1) + (human ? 0 : slot - N);
@@ -969,38 +964,12 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
         }
         // streaming stores: nobody on the device reads the rows, and what is not left dirty in the
         // L2s does not have to be written back before the next launch may start (-0.2 us per step)
-        if (R <= EBC_WAVE) {  // the wave's rows are one contiguous run of the output: leave through LDS
-          float *st = L.rows + stage_mis + (el * R + row) * T;
+        // (a lane's T floats are consecutive: the compiler stores them as 16-byte vectors)
+        float *o = io.obs_rotated + (ee * R + row) * T;
 #pragma unroll
-          for (int c = 0; c < T; ++c) st[c] = out[c];
-        } else {
-          float *o = io.obs_rotated + (ee * R + row) * T;
-#pragma unroll
-          for (int c = 0; c < T; ++c) __builtin_nontemporal_store(out[c], o + c);
-        }
+        for (int c = 0; c < T; ++c) __builtin_nontemporal_store(out[c], o + c);
       }
     }
-  }
-  // A lane's row is T floats 4 T bytes apart from its neighbour's: stored from the registers that is T
-  // wave instructions of scattered 4-byte writes, and the CU's memory pipeline is what the STATE waves
-  // next to this one are waiting on.  Staged, the wave's envs x R rows x T floats leave as 16-byte
-  // vectors of consecutive addresses (LDS index = output index mod 4, so both sides stay aligned).
-  if (R <= EBC_WAVE && stage_out) {
-    wave_sync();
-    const int nenv = s.E - (int)(block * epw) < (int)epw ? s.E - (int)(block * epw) : (int)epw;
-    const int total = nenv * R * T;
-    int lead = (4 - stage_mis) & 3;
-    lead = lead < total ? lead : total;
-    const int nvec = (total - lead) >> 2;
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    for (int q = lane; q < nvec; q += EBC_WAVE) {
-      const v4f v = *reinterpret_cast<const v4f *>(L.rows + stage_mis + lead + 4 * q);
-      __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(stage_out + lead + 4 * q));
-    }
-    const int tail = lead + 4 * nvec;  // < 4 floats before the first aligned vector, < 4 after the last
-    if (lane < lead) __builtin_nontemporal_store(L.rows[stage_mis + lane], stage_out + lane);
-    if (lane >= 4 && lane - 4 < total - tail)
-      __builtin_nontemporal_store(L.rows[stage_mis + tail + lane - 4], stage_out + tail + lane - 4);
   }
 }
 

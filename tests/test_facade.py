@@ -174,3 +174,31 @@ def test_known_answer_scenes_gpu():
                                   "traj_a5_linear_orcasub"])
 def test_golden_trajectory_gpu(name):
     _golden_trajectory(name, None)
+
+
+def test_save_load_map_roundtrip(tmp_path):
+    """tests/test_save_load_map.py:15-30 of the reference: reset() saving its generated scene,
+    a second env loading it -> equal occupancy maps; here also equal agents, static rows and the
+    same first observation."""
+    zs = load("scenes")
+    text = None
+    for k in range(int(zs["n"])):
+        m = json.loads(str(zs["meta_%d" % k]))
+        if m["config"].endswith("env_adults_5_bikes_5_static_5.config"):
+            text = m["config_text"]
+            break
+    assert text is not None
+    path = str(tmp_path / "scene.json")
+    env1, _ = _make(text, _oracle_backend)
+    ob1, _ = env1.reset("test", test_case=3, save_scene_path=path)
+    assert os.path.exists(path)
+    env2, _ = _make(text, _oracle_backend)
+    ob2, _ = env2.reset("test", load_scene_path=path)
+    assert env1.scene.map is not None and (env1.scene.map == 0).any()  # obstacles were placed
+    np.testing.assert_array_equal(env1.scene.map, env2.scene.map)
+    assert len(ob1) == len(ob2)
+    for a, b in zip(ob1, ob2):
+        assert (a.px, a.py, a.vx, a.vy, a.radius, a.obj_type) == (b.px, b.py, b.vx, b.vy, b.radius, b.obj_type)
+    for h1, h2 in zip(env1.scene.current.humans, env2.scene.current.humans):
+        assert (h1.gx, h1.gy, h1.v_pref, h1.type) == (h2.gx, h2.gy, h2.v_pref, h2.type)
+    np.testing.assert_array_equal(np.array(env1.scene.obstacle_vertices), np.array(env2.scene.obstacle_vertices))

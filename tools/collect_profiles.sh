@@ -19,6 +19,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
   rocprofv3 --pmc $grp --output-format csv -d $out/p$i -o p -- $B > $out/p$i.log 2>&1
 done
 python3 $root/profiles/summarize_pmc.py $out/p*/*counter_collection.csv > $out/pmc.json
+python3 $root/tools/traffic_from_pmc.py $out/pmc.json metric 4096 10 "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh $tag), bench.py --steps 300" > $out/traffic_metric.json
 cd $root
 python3 bench.py --steps 500 --warmup 20 > $out/bench_default.jsonl 2>$out/bench_default.err
 if [ -f eb-cadrl_amd/lib/libebcsim_trace.so ]; then
