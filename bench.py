@@ -129,6 +129,72 @@ def cpu_baseline(params, batch, seconds_target=7.0):
     return out
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def also_kernels(env, batch, dev):
+    """The two other kernels of the path with a roofline of their own, measured live (HIP events on
+    the launch stream; inputs resident in HBM): the 81-action look-ahead sweep whose rotated rows
+    are the one HBM-bound output of the path, and the value network's first block, which consumes
+    those rows on the bf16 matrix cores.  Reported beside the headline, never part of `value`."""
+    import torch
+    from ebcsim import _abi, actions as ebc_actions
+    from ebcsim.sarl import _NativeMlp2
+    out = []
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+
+    def timed(fn, n):
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    try:
+        space = ebc_actions.build_action_space(float(batch.robot[0, 7]))
+        A = len(space)
+        acts = torch.tensor(space, dtype=torch.float64, device=dev)
+        bufs = env.alloc_lookahead_outputs(A, ("reward", "done", "info", "rows_rotated"))
+        env.lookahead_device(acts, bufs, human_policy=_abi.HUMAN_ORCA)  # ORCA prelude -> cached velocities
+        sweep = lambda: env.lookahead_device(acts, bufs, human_policy=_abi.HUMAN_CACHED)  # noqa: E731
+        timed(sweep, 3)
+        ms = timed(sweep, 20)
+        # algorithmic bytes per env: the pre-step rows in (as the step), A x R x T floats + A x 10 B out
+        nbytes = env.E * (32 * batch.N + 44 + 16 * batch.S + 24 + A * (4 * env.T * env.R + 10))
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        out.append({"kernel": "lookahead_kernel: %d envs x %d actions, rotated rows [E][A][R][T] left in HBM "
+                              "(one launch, human velocities cached)" % (env.E, A),
+                    "launch_ms": ms,
+                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": nbytes}})
+        del bufs
+    except Exception as e:  # the headline line must still print
+        out.append({"kernel": "lookahead_kernel", "error": repr(e)})
+    try:
+        K0, H, O = env.T, 300, 200  # mlp1 of the reference's shipped eb-cadrl weights (data/eb-cadrl/rl_model_val.pth)
+        M = 1024 * 81 * env.R
+        g = torch.Generator(device="cpu").manual_seed(0)
+        w1 = torch.randn(H, K0, generator=g) / K0 ** 0.5
+        w2 = torch.randn(O, H, generator=g) / H ** 0.5
+        blk = _NativeMlp2([(w1, torch.randn(H, generator=g)), (w2, torch.randn(O, generator=g))], dev.index or 0)
+        x = torch.randn(M, K0, device=dev)
+        fwd = lambda: blk(x, True)  # noqa: E731
+        timed(fwd, 2)
+        ms = timed(fwd, 5)
+        f32_flops = 2.0 * M * (K0 * H + H * O)
+        tf = 3.0 * f32_flops / (ms * 1e-3) / 1e12  # three bf16 MFMA products per float32 product (split operands)
+        out.append({"kernel": "mlp2_split_wg_kernel: %d -> %d -> %d on %d rows (1024 envs x 81 actions x %d rows), "
+                              "float32 operands split into two bf16" % (K0, H, O, M, env.R),
+                    "launch_ms": ms,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / MFMA_BF16_PEAK_TFLOPS, "f32_equivalent_tflops": tf / 3.0}})
+    except Exception as e:
+        out.append({"kernel": "mlp2_split_wg_kernel", "error": repr(e)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +203,7 @@ def main():
     ap.add_argument("--workload", default="metric", choices=sorted(WORKLOADS))
     ap.add_argument("--envs", type=int, default=None, help="envs per GPU (default: workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the look-ahead / value-network side measurements")
     ap.add_argument("--human-policy", default="orca", choices=["orca", "linear"],
                     help="diagnostic only: the headline metric is ORCA")
     args = ap.parse_args()
@@ -194,8 +261,9 @@ def main():
     for _ in range(args.steps):
         env.step_device(outs, **kw)
     ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize()                 # this rank's K steps are done ...
+    elapsed = time.perf_counter() - t0       # ... its time; the job's time is the MAX over ranks (below)
+    barrier()                                # closing bracket: every rank is done
     stream_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels run on
 
     # per-launch kernel duration: HIP events around every launch, in a separate untimed pass
@@ -204,6 +272,10 @@ def main():
         env.step_device(outs, **kw)
     kernel_ms, n_timed = env.timing_read(reset=True)
     env.timing(False)
+
+    also = None
+    if rank == 0 and world == 1 and not args.no_also and args.human_policy == "orca":
+        also = also_kernels(env, batch, dev)
 
     from ebcsim import shard
     elapsed_max, total_humans = shard.job_rate(elapsed, float(batch.n_humans.sum()),
@@ -239,6 +311,8 @@ def main():
                          "launch_ms": launch_ms, "kernel_ms_event_pair": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
         }
+        if also is not None:
+            line["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(params, batch)
         print(json.dumps(line), flush=True)

@@ -819,6 +819,7 @@ struct StepGrid {
   unsigned env_blocks, orca_blocks, rows_blocks;  // then env_blocks STATE blocks
   unsigned rows_epw;                               // envs per ROWS wave (1 when N + S > 64)
   unsigned epoch;                                  // launch counter, never 0
+  unsigned total;                                  // one-wave "blocks" in all (EBC_STEP_WPB of them per workgroup)
 };
 
 #define EBC_RBN_ENVS 16  // envs per STATE wave whose restart robot is parked in LDS (more: late loads)
@@ -1139,14 +1140,22 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
 #ifndef EBC_STEP_WAVES
 #define EBC_STEP_WAVES(GS) ((GS) <= 9 ? 6 : 5)
 #endif
+// Waves per workgroup of the step launch.  Every wave is a "block" of its own (roles by index, no
+// workgroup barrier, a private LDS slice); packing several into one workgroup only changes how fast
+// the dispatcher starts them.
+#ifndef EBC_STEP_WPB
+#define EBC_STEP_WPB 1
+#endif
 template <int GS, int T>
-__global__ __launch_bounds__(EBC_WAVE, EBC_STEP_WAVES(GS)) void orca_step_kernel(EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
+__global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void orca_step_kernel(EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
   const WaveTrace wt(2);
-  constexpr size_t LDS = sizeof(RoleLds) > (size_t)OrcaLds<GS>::BYTES ? sizeof(RoleLds) : (size_t)OrcaLds<GS>::BYTES;
-  __shared__ __align__(16) unsigned char lds[LDS];
+  constexpr size_t LDS = ((sizeof(RoleLds) > (size_t)OrcaLds<GS>::BYTES ? sizeof(RoleLds) : (size_t)OrcaLds<GS>::BYTES) + 15) / 16 * 16;
+  __shared__ __align__(16) unsigned char lds_all[EBC_STEP_WPB][LDS];
+  unsigned char *lds = lds_all[threadIdx.x / EBC_WAVE];
   RoleLds &L = *reinterpret_cast<RoleLds *>(lds);
-  const int lane = threadIdx.x;
-  unsigned b = blockIdx.x;
+  const int lane = threadIdx.x & (EBC_WAVE - 1);
+  unsigned b = blockIdx.x * EBC_STEP_WPB + threadIdx.x / EBC_WAVE;
+  if (EBC_STEP_WPB > 1 && b >= g.total) return;
 #ifndef EBC_ROLE_MASK  // register-budget experiments: compile a subset of the roles
 #define EBC_ROLE_MASK 15
 #endif

@@ -165,9 +165,9 @@ int launch_service(Handle *h, const StepIO &io) {
 template <int GS>
 int launch_orca_step_gs(Handle *h, const StepIO &io, unsigned blocks, const ebc::StepGrid &g) {
   if (h->T == 17)
-    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 17>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, g);
+    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 17>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream, h->p, h->s, io, g);
   else
-    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 13>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, io, g);
+    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 13>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream, h->p, h->s, io, g);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
@@ -186,6 +186,7 @@ int launch_orca_step(Handle *h, const StepIO &io) {
   if (blocks >= 2147483648ull) return fail(EBC_ERR_UNSUPPORTED, "ORCA step grid >= 2^31 workgroups");
   if (++h->epoch == 0) h->epoch = 1;  // robot_ready boxes hold the epoch of the launch that filled them
   g.epoch = h->epoch;
+  g.total = (unsigned)blocks;
   const int rc = launch_orca_step_sized(h, io, blocks, g);
   // the launch leaves the robots' next state in robot_n: that is the current state from here on
   if (rc == EBC_OK) std::swap(h->s.robot, h->s.robot_n);

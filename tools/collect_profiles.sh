@@ -8,7 +8,7 @@ root=$PWD
 out=$root/gpurun_out/profiles_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $root/bench.py --no-cpu-baseline --steps 300 --warmup 20"
+B="python3 $root/bench.py --no-cpu-baseline --no-also --steps 300 --warmup 20"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B > $out/kt.log 2>&1
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
