@@ -237,6 +237,58 @@ __global__ __launch_bounds__(EBC_WAVE) void orca_kernel(EbcParams p, DevState s)
   }
 }
 
+// ORCA.predict with the ROBOT as the agent (simulator/policy/orca.py:85-157): the demonstrator of the
+// imitation-learning stage (rl/train.py:99-143 sets the policy's safety_space itself).  One GS-lane
+// group per env; lane j = row j of the observation the policy is given — the humans (env.py:381-382)
+// then the static obstacles as pedestrians (env.py:457-458, velocity 0) —, every radius + 0.01 +
+// safety_space as orca.py:116-126 hands it to rvo2, the robot's maxSpeed = v_pref.  -> act[E][2].
+template <int GS>
+__global__ __launch_bounds__(EBC_WAVE) void orca_robot_kernel(EbcParams p, DevState s, double safety_space, double *act) {
+  using L = OrcaLds<GS>;
+  constexpr int EPW = EBC_WAVE / GS;
+  __shared__ __align__(16) unsigned char scratch[L::BYTES];
+  float *dist_lds = reinterpret_cast<float *>(scratch);
+  float4 *lines_lds = reinterpret_cast<float4 *>(scratch + L::DIST);
+  float4 *segs_lds = lines_lds + L::GROUPS * L::Sh::LINES;
+  float4 *proj_lds = segs_lds + L::GROUPS * L::Sh::LINES;
+  const int group = threadIdx.x / GS, j = threadIdx.x - group * GS;
+  const int e = (int)blockIdx.x * EPW + group;
+  const bool e_ok = group < EPW && e < s.E;  // lanes past EPW * GS idle
+  const size_t ee = e_ok ? (size_t)e : 0;
+  const int N = s.N, S = s.S;
+  const int n = e_ok ? s.n_humans[ee] : 0;
+  const int ns = (e_ok && S) ? s.n_static[ee] : 0;
+  const double *rb = s.robot + ee * 9;
+  const float posx = (float)rb[0], posy = (float)rb[1], velx = (float)rb[2], vely = (float)rb[3];
+  const float radius = (float)(rb[4] + 0.01 + safety_space), maxSpeed = (float)rb[7];
+  float prefx, prefy;
+  orca_pref_velocity(rb[0], rb[1], rb[5], rb[6], prefx, prefy);
+  const bool valid = e_ok && j < n + ns;
+  float opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
+  if (valid && j < n) {
+    const size_t k = ee * N + j;
+    opx = (float)s.px[k];
+    opy = (float)s.py[k];
+    ovx = (float)s.vx[k];
+    ovy = (float)s.vy[k];
+    orad = (float)(s.radius[k] + 0.01 + safety_space);
+  } else if (valid) {
+    const size_t q = ee * S + (j - n);
+    opx = (float)s.spx[q];
+    opy = (float)s.spy[q];
+    orad = (float)(s.sradius[q] + 0.01 + safety_space);
+  }
+  float ox, oy;
+  orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy, ovx, ovy,
+                 orad, dist_lds + group * L::Sh::DIST, lines_lds + group * L::Sh::LINES,
+                 segs_lds + group * L::Sh::LINES, proj_lds + group * L::Sh::LINES, N + S, s.range_sq,
+                 s.inv_time_horizon, s.inv_time_step, ox, oy);
+  if (e_ok && j == 0) {
+    act[2 * ee] = (double)ox;  // getAgentVelocity -> Python float
+    act[2 * ee + 1] = (double)oy;
+  }
+}
+
 // ------------------------------------------------------------------------- step
 // The "service" work of a step, lane = human slot (floor(64 / N) envs per wave):
 //   service_env     robot action, swept robot-human distance with the humans' CURRENT velocity

@@ -601,6 +601,50 @@ int ebc_set_human_actions(void *handle, int location, const double *act) {
   return EBC_OK;
 }
 
+int ebc_robot_orca(void *handle, double safety_space, int location, double *action) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_robot_orca before ebc_reset");
+  if (!action) return fail(EBC_ERR_INVALID, "null action");
+  if (!(safety_space >= 0.0)) return fail(EBC_ERR_INVALID, "safety_space");
+  if (h->p.robot_kinematics != EBC_HOLONOMIC) return fail(EBC_ERR_UNSUPPORTED, "ORCA returns ActionXY: holonomic robots only");
+  const int others = h->s.N + h->s.S;  // rows of the observation
+  if (others > 32) return fail(EBC_ERR_UNSUPPORTED, "robot ORCA: more than 32 observation rows");
+  static const int sizes[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32};
+  int gs = 32;
+  for (int g : sizes)
+    if (g >= others) { gs = g; break; }
+  double *d_act = action;
+  Stager st{h};
+  if (location != EBC_DEVICE) {
+    if ((rc = ensure_stage(h, pad256((size_t)h->s.E * 2 * 8) + 1024)) != EBC_OK) return rc;
+    d_act = st.out(action, (size_t)h->s.E * 2);
+  }
+  const int epw = EBC_WAVE / gs;
+  const unsigned blocks = (unsigned)((h->s.E + epw - 1) / epw);
+#define RK_(GS) hipLaunchKernelGGL((ebc::orca_robot_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, safety_space, d_act)
+  switch (gs) {
+    case 2: RK_(2); break;
+    case 3: RK_(3); break;
+    case 4: RK_(4); break;
+    case 5: RK_(5); break;
+    case 6: RK_(6); break;
+    case 7: RK_(7); break;
+    case 8: RK_(8); break;
+    case 9: RK_(9); break;
+    case 10: RK_(10); break;
+    case 12: RK_(12); break;
+    case 16: RK_(16); break;
+    case 21: RK_(21); break;
+    default: RK_(32); break;
+  }
+#undef RK_
+  HIP_TRY(hipGetLastError());
+  if (location != EBC_DEVICE) return st.finish();
+  return EBC_OK;
+}
+
 int ebc_step(void *handle, const EbcStepArgs *a) {
   Handle *h;
   int rc = check_handle(handle, &h);

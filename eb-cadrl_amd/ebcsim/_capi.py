@@ -24,6 +24,7 @@ SYMBOLS = {
     "ebc_set_scene_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ebc_set_human_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ebc_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "ebc_robot_orca": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     "ebc_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_lookahead": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -159,6 +159,19 @@ class BatchedEnv:
         """Rotated observation of the current state into a torch CUDA tensor [E, R, T]."""
         _capi.check(self._L.ebc_observe(self._h, _abi.DEVICE, None, obs_rotated.data_ptr()))
 
+    def robot_orca(self, safety_space=0.0):
+        """ORCA.predict with the robot as the agent, every env (ebc_robot_orca) -> actions [E, 2]:
+        the imitation-learning demonstrator (rl/train.py:99-143)."""
+        act = np.zeros((self.E, 2))
+        _capi.check(self._L.ebc_robot_orca(self._h, float(safety_space), _abi.HOST, act.ctypes.data))
+        return act
+
+    def robot_orca_device(self, actions, safety_space=0.0):
+        """The same into a torch CUDA tensor float64 [E, 2] (enqueued on the handle's stream)."""
+        if actions.dtype.itemsize != 8 or actions.numel() != self.E * 2 or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous float64 [E, 2] tensor")
+        _capi.check(self._L.ebc_robot_orca(self._h, float(safety_space), _abi.DEVICE, actions.data_ptr()))
+
     def get_state(self):
         E, N = self.E, self.N
         f = lambda *s: np.zeros(s)  # noqa: E731

@@ -234,6 +234,14 @@ int ebc_set_human_actions(void *handle, int location, const double *act);
  * (rl/policy/multi_human_rl.py:128-149).  ob [E][R][5], obs_rotated [E][R][T]; either may be NULL. */
 int ebc_observe(void *handle, int location, double *ob, float *obs_rotated);
 
+/* ORCA.predict with the ROBOT as the agent, for every env (simulator/policy/orca.py:85-157 called
+ * through Robot.act, simulator/agents/robot.py:16-25): the demonstrator of the imitation-learning
+ * stage (rl/train.py:99-143, which sets the policy's safety_space itself; rl/utils/explorer.py:33-45).
+ * The others are the rows of the observation in their order: humans, then the static obstacles as
+ * pedestrians.  action [E][2] = ActionXY; feed it to ebc_step (EBC_ROBOT_EXTERNAL).  Holonomic robots,
+ * N + S <= 32. */
+int ebc_robot_orca(void *handle, double safety_space, int location, double *action);
+
 /* One env.step for every env (simulator/env.py:388-466), enqueued on the handle's stream.  With
  * EBC_HUMAN_ORCA it is ONE kernel launch whose arguments change from call to call (the robot state
  * is double-buffered and a launch counter travels with the launch): call it once per step; do not

@@ -61,6 +61,8 @@ def lib():
         L.orc_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_lookahead.restype = i
         L.orc_lookahead.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_robot_orca.restype = i
+        L.orc_robot_orca.argtypes = [C.c_void_p, C.c_void_p, d, C.c_void_p]
         L.orc_set_threads.restype = i
         L.orc_set_threads.argtypes = [i]
         _LIB = L
@@ -326,6 +328,15 @@ class OracleEnv:
         lib().orc_observe(C.addressof(self.params), C.addressof(self._state()), ob.ctypes.data,
                           obs.ctypes.data)
         return ob, obs
+
+    def robot_orca(self, safety_space=0.0):
+        """ORCA.predict for the robot of every env (orc_robot_orca) -> actions [E, 2]."""
+        act = np.zeros((self.E, 2))
+        rc = lib().orc_robot_orca(C.addressof(self.params), C.addressof(self._state()),
+                                  float(safety_space), act.ctypes.data)
+        if rc:
+            raise RuntimeError("orc_robot_orca failed: %d" % rc)
+        return act
 
     def get_state(self):
         keys = ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type", "n_humans",

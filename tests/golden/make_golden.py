@@ -462,7 +462,7 @@ def ob_rows(ob):
 
 def run_trajectory(ref, name, env_path, overrides, policy_cfg, robot_mode, n_steps, seed_case,
                    kinematics=None, orca=False, lookahead_every=0, scene_json=None,
-                   stop_when_done=False):
+                   stop_when_done=False, il_safety_space=0.0):
     """Drive the reference env and record everything the kernels must reproduce."""
     import torch
     from simulator.utils.action import ActionXY, ActionRot
@@ -475,15 +475,20 @@ def run_trajectory(ref, name, env_path, overrides, policy_cfg, robot_mode, n_ste
     text = cfg_text(os.path.join(ref, env_path), ov)
     cfg = parsed(text)
     pol_path = os.path.join(ref, policy_cfg)
-    env, pol, robot = make_env(ref, text, pol_path, policy="linear", kinematics=kinematics)
+    env, pol, robot = make_env(ref, text, pol_path, policy="orca" if robot_mode == "orca" else "linear",
+                               kinematics=kinematics)
+    if robot_mode == "orca":  # the imitation-learning demonstrator, rl/train.py:124-132
+        pol.multiagent_training = True
+        pol.safety_space = il_safety_space
     sarl = make_sarl(ref, policy_cfg, kinematics)   # rotate / transform / action space only
     sarl.time_step = cfg.getfloat("env", "time_step")
     kin = kinematics or "holonomic"
     if scene_json is not None:
-        ob, _ = env.reset("test", load_scene_path=os.path.join(ref, scene_json),
-                          compute_local_map=False)
+        ret = env.reset("test", load_scene_path=os.path.join(ref, scene_json), compute_local_map=False)
     else:
-        ob, _ = env.reset("test", test_case=seed_case, compute_local_map=False)
+        ret = env.reset("test", test_case=seed_case, compute_local_map=False)
+    ob = ret[0]  # (ob, local_map), or (ob, obstacle_vertices, local_map) for an ORCA robot (env.py:201-204)
+    assert len(ret) == (3 if robot_mode == "orca" else 2)
     sarl.build_action_space(robot.v_pref)
     space = sarl.action_space
     rs = np.random.RandomState(1000 + seed_case)
@@ -491,6 +496,7 @@ def run_trajectory(ref, name, env_path, overrides, policy_cfg, robot_mode, n_ste
     rec = {k: [] for k in ("action", "reward", "done", "info", "dmin", "dist_to_goal", "min_dist",
                            "robot", "humans", "time", "ob", "rot", "human_action", "arrival")}
     la = {k: [] for k in ("step", "reward", "done", "info", "next_ob", "rows")}
+    il_states = []
     for step in range(n_steps):
         if lookahead_every and step % lookahead_every == 0:
             rw, dn, inf, rows = [], [], [], []
@@ -504,8 +510,10 @@ def run_trajectory(ref, name, env_path, overrides, policy_cfg, robot_mode, n_ste
                 nxt = ob_rows(obs)
             la["step"].append(step); la["reward"].append(rw); la["done"].append(dn)
             la["info"].append(inf); la["next_ob"].append(nxt); la["rows"].append(np.array(rows))
-        if robot_mode == "linear":
+        if robot_mode in ("linear", "orca"):
             action = robot.act(ob, env=env)
+            if robot_mode == "orca":
+                il_states.append(pol.last_state)  # what Explorer.run_one_episode keeps (explorer.py:43-45)
         else:  # scripted: a seeded walk over the policy's own action space
             action = space[rs.randint(len(space))]
         prev = [(h.px, h.py) for h in humans_of(env)]
@@ -538,9 +546,22 @@ def run_trajectory(ref, name, env_path, overrides, policy_cfg, robot_mode, n_ste
         for k, v in la.items():
             out["la_" + k] = np.array(v)
         out["la_actions"] = np.array([[a[0], a[1]] for a in space])
+    if robot_mode == "orca":
+        # the imitation-learning memory of this episode, by the reference's own Explorer.update_memory
+        # (rl/utils/explorer.py:151-200, imitation_learning=True): transformed states and discounted returns
+        from rl.utils.explorer import Explorer
+        from rl.utils.memory import ReplayMemory
+        mem = ReplayMemory(100000)
+        sarl.set_device("cpu") if hasattr(sarl, "set_device") else None
+        ex = Explorer(env, robot, "cpu", mem, IL_GAMMA, target_policy=sarl)
+        ex.update_memory(il_states, [None] * len(il_states), [float(r) for r in rec["reward"]], True)
+        out["il_state"] = np.stack([m[0].numpy() for m in mem.memory])
+        out["il_value"] = np.array([float(m[1][0]) for m in mem.memory])
+        out["il_gamma"], out["robot_v_pref"] = np.array(IL_GAMMA), np.array(robot.v_pref)
     out["params"] = jdump(ebc_config.params_to_dict(params))
     out["meta"] = jdump({"config": env_path, "overrides": {"%s.%s" % k: v for k, v in ov.items()},
                          "policy_config": policy_cfg, "robot_mode": robot_mode,
+                         "il_safety_space": il_safety_space,
                          "human_policy": "orca(oracle-substituted rvo2)" if orca else "linear",
                          "seed_case": seed_case, "scene_json": scene_json, "kinematics": kin,
                          "final_info": int(rec["info"][-1])})
@@ -581,6 +602,19 @@ def gen_trajectories(ref):
     run_trajectory(ref, "traj_unicycle_rotpen", A5, rot,
                    "configs/policy_configs/policy_non_holonomic.config", "scripted", 40, 4,
                    kinematics="unicycle", lookahead_every=19)
+
+
+IL_GAMMA = 0.9  # [rl] gamma of the shipped policy configs
+
+
+def gen_il(ref):
+    """The imitation-learning demonstrator: the robot itself on ORCA (rvo2 substituted by the oracle's
+    restatement), invisible robot -> safety_space from the train config (rl/train.py:126-129;
+    configs/train_configs/*.config: 0.15); plus the episode's IL memory from the reference's Explorer."""
+    run_trajectory(ref, "traj_a5_il_orcasub", A5, None, P1, "orca", 120, 4, orca=True, il_safety_space=0.15,
+                   stop_when_done=True)
+    run_trajectory(ref, "traj_n10_walls_il_orcasub", BIG, N10, P17, "orca", 160, 2, orca=True,
+                   il_safety_space=0.15, stop_when_done=True)
 
 
 # --------------------------------------------- (viii) the reference's known-answer scenes
@@ -709,7 +743,7 @@ def gen_local_map(ref):
 
 GENERATORS = {"collisions": gen_collisions, "reward": gen_reward, "grid": gen_grid,
               "rotate": gen_rotate, "action_space": gen_action_space, "scenes": gen_scenes,
-              "trajectories": gen_trajectories, "known": gen_known_answers, "sarl": gen_sarl, "local_map": gen_local_map}
+              "trajectories": gen_trajectories, "il": gen_il, "known": gen_known_answers, "sarl": gen_sarl, "local_map": gen_local_map}
 
 
 def main():

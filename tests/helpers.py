@@ -53,6 +53,8 @@ TRAJ_PINNED = ["traj_a5_linear", "traj_a5_scripted", "traj_a3b3s2_scripted", "tr
                "traj_unicycle_rotpen"]
 TRAJ_ORCASUB = ["traj_a5_linear_orcasub", "traj_a5_scripted_orcasub",
                 "traj_a3b3s2_scripted_orcasub", "traj_n10_walls_t17_orcasub"]
+# the imitation-learning demonstrator: the robot itself on ORCA (rl/train.py:99-143)
+TRAJ_IL = ["traj_a5_il_orcasub", "traj_n10_walls_il_orcasub"]
 
 
 def check_trajectory(env, z, atol=1e-9, rot_atol=1e-5, lookahead=True):
@@ -63,7 +65,17 @@ def check_trajectory(env, z, atol=1e-9, rot_atol=1e-5, lookahead=True):
     n = len(z["init_px"])
     ns = len(z["init_static"].reshape(-1, 3))
     la_steps = list(z["la_step"]) if ("la_step" in z.files and lookahead) else []
+    meta = json.loads(str(z["meta"]))
+    robot_orca = meta.get("robot_mode") == "orca"
     for t in range(len(z["action"])):
+        if robot_orca:
+            # the demonstrator's action (Robot.act -> ORCA.predict) and the state the explorer keeps
+            # for the imitation-learning memory (policy.last_state, transformed)
+            a = env.robot_orca(meta["il_safety_space"])
+            np.testing.assert_allclose(a[0], z["action"][t], atol=atol, rtol=0, err_msg="robot ORCA, step %d" % t)
+            assert (a == a[0:1]).all()
+            np.testing.assert_allclose(env.observe()[1][0][:n + ns], z["il_state"][t], atol=rot_atol,
+                                       rtol=rot_atol, err_msg="IL state, step %d" % t)
         if t in la_steps:
             k = la_steps.index(t)
             la = env.lookahead(z["la_actions"], human_policy=pol)

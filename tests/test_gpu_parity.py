@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from ebcsim import _abi, actions as ebc_actions, config as ebc_config, scene as ebc_scene
-from helpers import (GOLDEN, TRAJ_ORCASUB, TRAJ_PINNED, batch_from_init, check_trajectory, load,
+from helpers import (GOLDEN, TRAJ_IL, TRAJ_ORCASUB, TRAJ_PINNED, batch_from_init, check_trajectory, load,
                      params_of)
 
 pytestmark = pytest.mark.gpu
@@ -21,7 +21,7 @@ def _env(params, E, N, S):
     return BatchedEnv(params, E, N, S)
 
 
-@pytest.mark.parametrize("name", TRAJ_PINNED + TRAJ_ORCASUB)
+@pytest.mark.parametrize("name", TRAJ_PINNED + TRAJ_ORCASUB + TRAJ_IL)
 def test_golden_trajectories(name):
     z = load(name)
     b = batch_from_init(z, copies=3)
@@ -515,3 +515,36 @@ def test_scene_pool_auto_reset():
     ob_g, obs_g = g.observe()
     ob_o, obs_o = o.observe()
     np.testing.assert_array_equal(ob_g, ob_o)
+
+
+@pytest.mark.parametrize("fixture,E,steps,safety", [
+    ("traj_a5_il_orcasub", 200, 60, 0.15),          # 5 rows: 5-lane groups
+    ("traj_n10_walls_il_orcasub", 150, 90, 0.15),   # 18 rows (ragged static rows): 21-lane groups
+    ("traj_a3b3s2_scripted_orcasub", 77, 50, 0.0),  # visible-robot style safety 0
+])
+def test_robot_orca_rollouts_vs_oracle(fixture, E, steps, safety):
+    """The imitation-learning demonstrator on the device (ebc_robot_orca -> ebc_step) against the
+    oracle on seeded random scenes, restarts included: the robot's ORCA action every step, bit for
+    bit, and the episode it produces; host buffers and device-resident tensors."""
+    import torch
+    from oracle import oracle
+    z = load(fixture)
+    params = params_of(z)
+    b, cfg = _random_batch(_config_text(json.loads(str(z["meta"]))), [5000 + e for e in range(E)])
+    g = _env(params, E, b.N, b.S)
+    o = oracle.OracleEnv(params, E, b.N, b.S)
+    g.reset(b)
+    o.reset(b)
+    dev_act = torch.zeros((E, 2), dtype=torch.float64, device="cuda")
+    kinds = set()
+    for t in range(steps):
+        ag, ao = g.robot_orca(safety), o.robot_orca(safety)
+        np.testing.assert_array_equal(ag, ao, err_msg="robot ORCA step %d" % t)
+        g.robot_orca_device(dev_act, safety)
+        g.synchronize()
+        np.testing.assert_array_equal(dev_act.cpu().numpy(), ao)
+        og = g.step(robot_action=ag, human_policy=_abi.HUMAN_ORCA, flags=_abi.FLAG_AUTO_RESET)
+        oo = o.step(robot_action=ao, human_policy=_abi.HUMAN_ORCA, flags=_abi.FLAG_AUTO_RESET)
+        _compare_step(og, oo, "%s step %d" % (fixture, t))
+        kinds.update(og["info"].tolist())
+    assert len(kinds) >= 2

@@ -10,7 +10,7 @@ import pytest
 
 from ebcsim import _abi, actions as ebc_actions, config as ebc_config, scene as ebc_scene
 from oracle import oracle
-from helpers import (GOLDEN, TRAJ_ORCASUB, TRAJ_PINNED, batch_from_init, check_trajectory, load,
+from helpers import (GOLDEN, TRAJ_IL, TRAJ_ORCASUB, TRAJ_PINNED, batch_from_init, check_trajectory, load,
                      params_of)
 
 
@@ -135,6 +135,19 @@ def test_trajectory_pinned(name):
 def test_trajectory_orca_substituted(name):
     """Reference orchestration around ORCA (rvo2 replaced by the oracle's restatement):
     pins marshalling/order/update, NOT ORCA arithmetic (unpinned)."""
+    z = load(name)
+    params = params_of(z)
+    b = batch_from_init(z)
+    env = oracle.OracleEnv(params, 1, b.N, b.S)
+    env.reset(b)
+    check_trajectory(env, z, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", TRAJ_IL)
+def test_trajectory_robot_on_orca(name):
+    """The imitation-learning demonstrator: Robot.act -> ORCA.predict over the returned observation
+    (humans + static obstacles as pedestrians), rvo2 replaced by the oracle's restatement, and the
+    states the reference's explorer keeps for the IL memory."""
     z = load(name)
     params = params_of(z)
     b = batch_from_init(z)
