@@ -72,13 +72,43 @@ class DeviceHumanPolicy(Policy):
             "of the accelerated path" % self.name)
 
 
+class ORCA(DeviceHumanPolicy):
+    """simulator/policy/orca.py:8-157.  In a human section it is the marker above (EBC_HUMAN_ORCA in the
+    kernels).  Given to the ROBOT (`robot.set_policy(policy_factory["orca"]())`, the imitation-learning
+    demonstrator of rl/train.py:99-143) its predict() is ebc_robot_orca on the env's backend: the
+    robot's ORCA velocity against the rows of the current observation (humans, then the static
+    obstacles as pedestrians), radii + 0.01 + safety_space."""
+
+    def __init__(self):
+        from . import _abi
+        DeviceHumanPolicy.__init__(self, "ORCA", _abi.HUMAN_ORCA)
+        self.trainable = False
+        self.multiagent_training = None
+        self.safety_space = 0
+        self.neighbor_dist, self.max_neighbors = 10, 10  # orca.py:64-69: what the kernels use (EbcParams)
+        self.time_horizon = self.time_horizon_obst = 5
+        self.radius, self.max_speed = 0.3, 200
+
+    def predict(self, state, env=None):
+        """`state` must be the env's current joint state (Robot.act builds it from the observation the
+        env has just returned): the arithmetic reads the device-resident copy of it."""
+        if env is None or getattr(env, "_backend", None) is None:
+            raise ValueError("ORCA as a robot policy needs the env it acts in (robot.act(ob, env=env)) after reset()")
+        s = state.self_state
+        rb = env._backend.get_state()["robot"][0]
+        if (s.px, s.py, s.gx, s.gy) != (rb[0], rb[1], rb[5], rb[6]):
+            raise ValueError("ORCA.predict: the state passed in is not the env's current state")
+        vx, vy = env._backend.robot_orca(self.safety_space)[0]
+        self.last_state = state
+        return ActionXY(float(vx), float(vy))
+
+
 def none_policy():
     return None
 
 
 def _orca():
-    from . import _abi
-    return DeviceHumanPolicy("ORCA", _abi.HUMAN_ORCA)
+    return ORCA()
 
 
 policy_factory = {"linear": Linear, "orca": _orca, "none": none_policy}

@@ -1,9 +1,12 @@
 """Data-parallel value-network training on device-resident rollouts (BASELINE config 5).
 
-Mirrors, batched: the replay memory (rl/utils/memory.py:4-28), the value targets of
-Explorer.update_memory in RL mode (rl/utils/explorer.py:151-200: terminal -> reward, else
-reward + gamma^(dt * v_pref) * V_target(next state)), and Trainer.optimize_batch
-(rl/utils/trainer.py:74-100: MSE regression, SGD momentum 0.9 or Adam).
+Mirrors, batched: the replay memory (rl/utils/memory.py:4-28); the value targets of
+Explorer.update_memory (rl/utils/explorer.py:151-200) in both modes — imitation learning: the
+episode's discounted return from each step on; RL: terminal -> reward, else reward +
+gamma^(dt * v_pref) * V_target(next state) —; Trainer.optimize_epoch / optimize_batch
+(rl/utils/trainer.py:45-100: MSE regression, SGD momentum 0.9 or Adam); and the schedule of
+rl/train.py:99-260 (imitation learning with the robot on ORCA, then epsilon-greedy RL with a
+target network) as `run_training`.
 
 Multi-GPU: every rank rolls out its own env slice (no collective on the sim path) and holds its
 own replay shard; the only exchange is ONE all-reduce of the flattened gradient per optimizer
@@ -101,6 +104,26 @@ def value_targets(reward, done, next_states, target_net, gamma_bar):
     return torch.where(done.bool(), reward, reward + gamma_bar * nxt.to(reward.dtype))
 
 
+def il_value_targets(rewards, done, gamma_bar):
+    """Imitation-learning targets (explorer.py:159-170): value_i = sum over the REST OF ITS EPISODE
+    of gamma_bar^(t - i) * reward_t, gamma_bar = gamma^(dt * v_pref).  rewards, done: [T, E] in time
+    order, episodes of an env following one another (auto-reset).  Returns (values [T, E], complete
+    [T, E]): `complete` marks the steps whose episode ended inside the window — the reference only ever
+    stores whole episodes (explorer.py:33-92)."""
+    T = rewards.shape[0]
+    values = torch.zeros_like(rewards)
+    complete = torch.zeros_like(done, dtype=torch.bool)
+    run = torch.zeros_like(rewards[0])
+    closed = torch.zeros_like(done[0], dtype=torch.bool)
+    for t in range(T - 1, -1, -1):
+        d = done[t].bool()
+        run = torch.where(d, rewards[t], rewards[t] + gamma_bar * run)
+        closed = closed | d
+        values[t] = run
+        complete[t] = closed
+    return values, complete
+
+
 def allreduce_flat_(params):
     """Average the gradients of `params` over ranks with ONE all-reduce of a flat buffer."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -126,6 +149,40 @@ class DataParallelTrainer(object):
         else:
             self.optimizer = torch.optim.SGD(params, lr=learning_rate, momentum=0.9)
         self.criterion = torch.nn.MSELoss()
+
+    def set_learning_rate(self, learning_rate):
+        """Trainer.set_optimizer (trainer.py:24-43): a new optimizer at the stage's learning rate."""
+        params = list(self.model.parameters())
+        if isinstance(self.optimizer, torch.optim.Adam):
+            self.optimizer = torch.optim.Adam(params, lr=learning_rate)
+        else:
+            self.optimizer = torch.optim.SGD(params, lr=learning_rate, momentum=0.9)
+
+    def optimize_epoch(self, num_epochs, generator=None):
+        """Trainer.optimize_epoch (trainer.py:45-72, imitation learning): `num_epochs` shuffled passes
+        over the memory in batches.  Every rank walks its own shard; the gradient of each batch is
+        averaged over ranks, so all ranks take the same number of batches (the smallest shard's)."""
+        params = list(self.model.parameters())
+        n = len(self.memory)
+        batches = (n + self.batch_size - 1) // self.batch_size
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([batches], dtype=torch.int64, device=self.memory.states.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            batches = int(t.item())
+        average = 0.0
+        for _ in range(num_epochs):
+            perm = torch.randperm(n, device=self.memory.states.device, generator=generator)
+            epoch_loss = 0.0
+            for b in range(batches):
+                idx = perm[b * self.batch_size:(b + 1) * self.batch_size]
+                self.optimizer.zero_grad()
+                loss = self.criterion(self.model(self.memory.states[idx]), self.memory.values[idx])
+                loss.backward()
+                allreduce_flat_(params)
+                self.optimizer.step()
+                epoch_loss += float(loss.detach())
+            average = epoch_loss / max(n, 1)  # trainer.py:69: divided by len(memory), as the reference does
+        return average
 
     def optimize_batch(self, num_batches, generator=None):
         losses = 0.0
@@ -169,3 +226,69 @@ def collect(env, policy, target_net, memory, steps, gamma, epsilon=0.0, generato
         # the next decision's state: the returned observation, or the reset scene after a terminal step
         env.observe_device(cur)
     return total / steps
+
+
+def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HUMAN_ORCA):
+    """The imitation-learning stage's rollouts (rl/train.py:124-133, explorer.py:33-92 with
+    imitation_learning=True): the robot of every env of the rank's slice on ORCA (ebc_robot_orca ->
+    ebc_step, auto-reset) for `steps` steps; the states of every episode that ended inside the window
+    go to `memory` with their discounted returns.  Returns (steps stored, episodes ended)."""
+    dev = memory.states.device
+    E, R, T = env.E, env.R, env.T
+    states = torch.zeros((steps, E, R, T), dtype=torch.float32, device=dev)
+    rewards = torch.zeros((steps, E), dtype=torch.float64, device=dev)
+    dones = torch.zeros((steps, E), dtype=torch.uint8, device=dev)
+    act = torch.zeros((E, 2), dtype=torch.float64, device=dev)
+    outs = env.alloc_step_outputs(("reward", "done", "info"))
+    v_pref = float(env.get_state()["robot"][0, 7])
+    gamma_bar = gamma ** (env.params.time_step * v_pref)
+    for t in range(steps):
+        env.observe_device(states[t])        # policy.last_state, transformed (explorer.py:43, :162)
+        env.robot_orca_device(act, safety_space)
+        env.step_device(outs, robot_action=act, human_policy=human_policy, flags=_abi.FLAG_AUTO_RESET)
+        rewards[t].copy_(outs["reward"])
+        dones[t].copy_(outs["done"])
+    values, complete = il_value_targets(rewards, dones, gamma_bar)
+    keep = complete.reshape(-1)
+    memory.push(states.reshape(steps * E, R, T)[keep], values.reshape(-1)[keep])
+    return int(keep.sum()), int(dones.sum())
+
+
+def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learning_rate=0.01, il_safety_space=0.15,
+                 rl_learning_rate=0.001, train_iterations=0, steps_per_iteration=1, train_batches=100,
+                 batch_size=100, capacity=100000, epsilon_start=0.5, epsilon_end=0.1, epsilon_decay=4000,
+                 target_update_interval=50, optimizer_algorithm="sgd", generator=None, log=None):
+    """The schedule of rl/train.py:99-260 on one rank's env slice (every rank calls it; gradients are
+    averaged over ranks inside the trainer): imitation learning with the robot on ORCA
+    (`il_steps` steps of every env, then `il_epochs` passes over the memory), then `train_iterations`
+    rounds of [epsilon-greedy rollout of `steps_per_iteration` decisions per env -> `train_batches`
+    optimizer steps], the target network refreshed every `target_update_interval` rounds, epsilon
+    decayed linearly over `epsilon_decay` rounds (train.py:211-218).  env: BatchedEnv with auto-reset
+    semantics, on the model's device.  Returns a dict of what happened."""
+    from .sarl import DeviceSarlPolicy
+    dev = next(model.parameters()).device
+    memory = DeviceReplay(capacity, env.R, env.T, dev)
+    trainer = DataParallelTrainer(model, memory, batch_size, optimizer_algorithm, il_learning_rate)
+    hist = {"il_stored": 0, "il_episodes": 0, "il_loss": None, "rl_loss": [], "mean_reward": []}
+    if il_steps > 0:
+        hist["il_stored"], hist["il_episodes"] = collect_il(env, memory, il_steps, gamma, il_safety_space)
+        if len(memory) and il_epochs > 0:
+            hist["il_loss"] = trainer.optimize_epoch(il_epochs, generator)
+        if log:
+            log("imitation learning: %d states of %d episodes, loss %s" % (hist["il_stored"], hist["il_episodes"], hist["il_loss"]))
+    import copy
+    target = copy.deepcopy(model)                      # explorer.update_target_model (train.py:195)
+    trainer.set_learning_rate(rl_learning_rate)
+    policy = DeviceSarlPolicy(model.as_value_net(), actions, gamma)
+    for it in range(train_iterations):
+        eps = epsilon_start + (epsilon_end - epsilon_start) / epsilon_decay * it if it < epsilon_decay else epsilon_end
+        mean_r = collect(env, policy, target.as_value_net(), memory, steps_per_iteration, gamma, epsilon=eps,
+                         generator=generator)
+        loss = trainer.optimize_batch(train_batches, generator)
+        if (it + 1) % target_update_interval == 0:
+            target.load_state_dict(model.state_dict())
+        hist["rl_loss"].append(loss)
+        hist["mean_reward"].append(mean_r)
+        if log:
+            log("iteration %d: epsilon %.3f mean reward %.4f loss %.3e" % (it, eps, mean_r, loss))
+    return hist

@@ -202,3 +202,56 @@ def test_save_load_map_roundtrip(tmp_path):
     for h1, h2 in zip(env1.scene.current.humans, env2.scene.current.humans):
         assert (h1.gx, h1.gy, h1.v_pref, h1.type) == (h2.gx, h2.gy, h2.v_pref, h2.type)
     np.testing.assert_array_equal(np.array(env1.scene.obstacle_vertices), np.array(env2.scene.obstacle_vertices))
+
+
+def _il_episode(name, backend):
+    """rl/utils/explorer.py:33-45 with the robot on ORCA (rl/train.py:124-132): reset() returns
+    (ob, obstacle_vertices, local_map); robot.act -> ORCA.predict -> env.step, call for call."""
+    import io
+    z = load(name)
+    meta = json.loads(str(z["meta"]))
+    zs = load("scenes")
+    text = None
+    for k in range(int(zs["n"])):
+        m = json.loads(str(zs["meta_%d" % k]))
+        if m["config"] == meta["config"]:
+            cfg = configparser.RawConfigParser()
+            cfg.read_string(m["config_text"])
+            for key, val in meta["overrides"].items():
+                sec, opt = key.split(".")
+                cfg.set(sec, opt, str(val))
+            buf = io.StringIO()
+            cfg.write(buf)
+            text = buf.getvalue()
+            break
+    env, robot = _make(text, backend)
+    pol = policy_factory["orca"]()
+    pol.multiagent_training = True
+    pol.safety_space = meta["il_safety_space"]
+    robot.set_policy(pol)
+    ret = env.reset("test", test_case=meta["seed_case"])
+    assert len(ret) == 3  # env.py:201-204
+    ob, vertices, local_map = ret
+    assert vertices is env.scene.obstacle_vertices
+    done, t = False, 0
+    while not done:
+        action = robot.act(ob, local_map=local_map, env=env)
+        assert isinstance(action, ActionXY)
+        np.testing.assert_allclose([action.vx, action.vy], z["action"][t], atol=1e-12)
+        assert pol.last_state.self_state.px == robot.px
+        ob, local_map, reward, done, info = env.step(action)
+        np.testing.assert_allclose(reward, z["reward"][t], atol=1e-9)
+        t += 1
+    assert t == len(z["action"])
+    assert int(z["info"][-1]) == {"ReachGoal": 2, "Timeout": 7}[type(info).__name__]
+
+
+@pytest.mark.parametrize("name", ["traj_a5_il_orcasub", "traj_n10_walls_il_orcasub"])
+def test_imitation_learning_episode_cpu_backend(name):
+    _il_episode(name, _oracle_backend)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["traj_a5_il_orcasub", "traj_n10_walls_il_orcasub"])
+def test_imitation_learning_episode_gpu(name):
+    _il_episode(name, None)

@@ -126,3 +126,69 @@ def test_collect_and_train_on_device():
     first = tr.optimize_batch(20, g)
     last = tr.optimize_batch(20, g)
     assert np.isfinite(first) and np.isfinite(last) and last < first * 1.5
+
+
+def test_imitation_learning_targets_match_reference():
+    """Explorer.update_memory(imitation_learning=True) (explorer.py:159-170) on the reference's own IL
+    episodes (golden, robot on ORCA): the discounted return from every step on; and the batched form:
+    episodes of different lengths following one another, the unfinished tail left out."""
+    from helpers import load
+    from ebcsim.train import il_value_targets
+    for name in ("traj_a5_il_orcasub", "traj_n10_walls_il_orcasub"):
+        z = load(name)
+        gb = float(z["il_gamma"]) ** (0.25 * float(z["robot_v_pref"]))
+        r = torch.tensor(z["reward"])[:, None]
+        d = torch.tensor(z["done"].astype(np.uint8))[:, None]
+        v, c = il_value_targets(r, d, gb)
+        assert bool(c.all())
+        np.testing.assert_allclose(v[:, 0].numpy(), z["il_value"], atol=1e-6)
+    # two envs: env 0 = episode of 3 steps, then 2 steps, then an unfinished one; env 1 never ends
+    r = torch.tensor([[1.0, 0.5], [0.0, 0.5], [2.0, 0.5], [1.0, 0.5], [3.0, 0.5], [7.0, 0.5]], dtype=torch.float64)
+    d = torch.tensor([[0, 0], [0, 0], [1, 0], [0, 0], [1, 0], [0, 0]], dtype=torch.uint8)
+    v, c = il_value_targets(r, d, 0.5)
+    np.testing.assert_allclose(v[:, 0].numpy(), [1 + 0.25 * 2, 0.5 * 2, 2.0, 1 + 0.5 * 3, 3.0, 7.0])
+    assert c[:, 0].tolist() == [True, True, True, True, True, False] and not c[:, 1].any()
+
+
+def test_optimize_epoch_walks_the_memory():
+    """Trainer.optimize_epoch (trainer.py:45-72): every stored pair once per epoch; the loss falls."""
+    from ebcsim.train import DataParallelTrainer, DeviceReplay, SarlModule
+    torch.manual_seed(0)
+    model = SarlModule(**DIMS)
+    x, y = _data(5, 96)
+    mem = DeviceReplay(128, 5, 13, "cpu")
+    mem.push(x, 0.1 * y)
+    tr = DataParallelTrainer(model, mem, 32, "sgd", 0.01)
+    g = torch.Generator().manual_seed(3)
+    first = tr.optimize_epoch(1, g)
+    last = tr.optimize_epoch(5, g)
+    assert np.isfinite(first) and last < first
+
+
+@pytest.mark.gpu
+def test_run_training_imitation_then_rl_on_device():
+    """rl/train.py:99-260 in small: the robot on ORCA fills the memory with whole episodes and their
+    returns, epochs over it, then epsilon-greedy RL rounds against a target network."""
+    import json
+    from helpers import GOLDEN, batch_from_init, load, params_of
+    from ebcsim.batched import BatchedEnv
+    from ebcsim.train import SarlModule, run_training
+    z = load("sarl_a5_baseline")
+    meta = json.loads(str(z["meta"]))
+    E = 64
+    b = batch_from_init(z, copies=E)
+    env = BatchedEnv(params_of(z), E, b.N, b.S)
+    env.reset(b)
+    env.use_torch_stream()
+    model = SarlModule(**DIMS).to("cuda:0")
+    g = torch.Generator(device="cuda:0").manual_seed(1)
+    lines = []
+    hist = run_training(env, model, z["action_space"], meta["gamma"], il_steps=150, il_epochs=3,
+                        il_learning_rate=0.01, il_safety_space=0.15, rl_learning_rate=0.001,
+                        train_iterations=3, steps_per_iteration=4, train_batches=5, batch_size=100,
+                        capacity=20000, epsilon_start=0.5, epsilon_end=0.1, epsilon_decay=2,
+                        target_update_interval=2, generator=g, log=lines.append)
+    assert hist["il_episodes"] >= E and hist["il_stored"] > 0
+    assert hist["il_loss"] is not None and np.isfinite(hist["il_loss"])
+    assert len(hist["rl_loss"]) == 3 and all(np.isfinite(v) for v in hist["rl_loss"])
+    assert len(lines) == 4
