@@ -104,24 +104,64 @@ def value_targets(reward, done, next_states, target_net, gamma_bar):
     return torch.where(done.bool(), reward, reward + gamma_bar * nxt.to(reward.dtype))
 
 
-def il_value_targets(rewards, done, gamma_bar):
+def stored_episode(info):
+    """explorer.py:82-92: an episode's experience is stored only when it ended in ReachGoal or in a
+    collision — not on a timeout.  info: EBC_INFO_* codes of terminal steps."""
+    return ((info == _abi.INFO_REACH_GOAL) | (info == _abi.INFO_COLLISION_OBSTACLE) | (info == _abi.INFO_COLLISION_ADULT)
+            | (info == _abi.INFO_COLLISION_BICYCLE) | (info == _abi.INFO_COLLISION_CHILD))
+
+
+def il_value_targets(rewards, done, gamma_bar, info=None):
     """Imitation-learning targets (explorer.py:159-170): value_i = sum over the REST OF ITS EPISODE
     of gamma_bar^(t - i) * reward_t, gamma_bar = gamma^(dt * v_pref).  rewards, done: [T, E] in time
-    order, episodes of an env following one another (auto-reset).  Returns (values [T, E], complete
-    [T, E]): `complete` marks the steps whose episode ended inside the window — the reference only ever
-    stores whole episodes (explorer.py:33-92)."""
+    order, episodes of an env following one another (auto-reset).  Returns (values [T, E], keep
+    [T, E]): `keep` marks the steps whose episode ended inside the window — the reference only ever
+    stores whole episodes (explorer.py:33-92) — and, when the steps' info codes are given, ended in
+    ReachGoal or a collision (`stored_episode`)."""
     T = rewards.shape[0]
     values = torch.zeros_like(rewards)
-    complete = torch.zeros_like(done, dtype=torch.bool)
+    keep = torch.zeros_like(done, dtype=torch.bool)
     run = torch.zeros_like(rewards[0])
     closed = torch.zeros_like(done[0], dtype=torch.bool)
     for t in range(T - 1, -1, -1):
         d = done[t].bool()
         run = torch.where(d, rewards[t], rewards[t] + gamma_bar * run)
-        closed = closed | d
+        closed = torch.where(d, torch.ones_like(d) if info is None else stored_episode(info[t]), closed)
         values[t] = run
-        complete[t] = closed
-    return values, complete
+        keep[t] = closed
+    return values, keep
+
+
+class EpisodeStore(object):
+    """Where an env's (state, value) pairs wait for their episode's end: the reference pushes an episode
+    to the replay memory when it is over, and only if it ended in ReachGoal or a collision
+    (explorer.py:82-92).  [T_max][E] slots in device memory, one write cursor per env."""
+
+    def __init__(self, E, T_max, R, T, device):
+        self.states = torch.zeros((T_max, E, R, T), dtype=torch.float32, device=device)
+        self.values = torch.zeros((T_max, E), dtype=torch.float32, device=device)
+        self.length = torch.zeros(E, dtype=torch.int64, device=device)
+        self.T_max, self.E = int(T_max), int(E)
+        self._env = torch.arange(E, device=device)
+        self._t = torch.arange(T_max, device=device)[:, None]
+
+    def add(self, states, values):
+        t = self.length.clamp(max=self.T_max - 1)  # an episode cannot outlast time_limit / time_step steps
+        self.states[t, self._env] = states
+        self.values[t, self._env] = values.to(torch.float32)
+        self.length = (self.length + 1).clamp(max=self.T_max)
+
+    def end(self, done, info, memory):
+        """After a step: episodes that ended go to `memory` (or are dropped); returns how many pairs went."""
+        done = done.bool()
+        go = done & stored_episode(info)
+        n = 0
+        if bool(go.any()):
+            mask = (self._t < self.length[None, :]) & go[None, :]
+            n = int(mask.sum())
+            memory.push(self.states[mask], self.values[mask])
+        self.length = torch.where(done, torch.zeros_like(self.length), self.length)
+        return n
 
 
 def allreduce_flat_(params):
@@ -199,10 +239,12 @@ class DataParallelTrainer(object):
 
 
 def collect(env, policy, target_net, memory, steps, gamma, epsilon=0.0, generator=None,
-            human_policy=_abi.HUMAN_ORCA):
+            human_policy=_abi.HUMAN_ORCA, store=None):
     """Roll the rank's env slice `steps` decisions forward with an epsilon-greedy SARL policy
     (multi_human_rl.py:31-33, :84-85) and push (state, value target) pairs.  env: BatchedEnv on
-    the policy's device with auto-reset; returns the mean reward."""
+    the policy's device with auto-reset; returns the mean reward.  With an EpisodeStore the pairs
+    reach the memory as the reference's do: per finished episode, successes and collisions only;
+    without one every step's pair goes in at once."""
     dev = policy.net.device
     E, R, T = env.E, env.R, env.T
     cur = torch.zeros((E, R, T), dtype=torch.float32, device=dev)
@@ -221,7 +263,11 @@ def collect(env, policy, target_net, memory, steps, gamma, epsilon=0.0, generato
         env.step_device(outs, robot_action=actions.contiguous(), human_policy=_abi.HUMAN_CACHED,
                         flags=_abi.FLAG_AUTO_RESET)
         targets = value_targets(outs["reward"], outs["done"], outs["obs_rotated"], target_net, gamma_bar)
-        memory.push(cur.clone(), targets)
+        if store is None:
+            memory.push(cur.clone(), targets)
+        else:
+            store.add(cur, targets)
+            store.end(outs["done"], outs["info"], memory)
         total += float(outs["reward"].mean())
         # the next decision's state: the returned observation, or the reset scene after a terminal step
         env.observe_device(cur)
@@ -231,14 +277,16 @@ def collect(env, policy, target_net, memory, steps, gamma, epsilon=0.0, generato
 def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HUMAN_ORCA):
     """The imitation-learning stage's rollouts (rl/train.py:124-133, explorer.py:33-92 with
     imitation_learning=True): the robot of every env of the rank's slice on ORCA (ebc_robot_orca ->
-    ebc_step, auto-reset) for `steps` steps; the states of every episode that ended inside the window
-    go to `memory` with their discounted returns.  Returns (steps stored, episodes ended)."""
+    ebc_step, auto-reset) for `steps` steps; the states of every episode that ended inside the window in
+    ReachGoal or a collision (explorer.py:82-92) go to `memory` with their discounted returns.  Returns
+    (steps stored, episodes ended)."""
     dev = memory.states.device
     E, R, T = env.E, env.R, env.T
     states = torch.zeros((steps, E, R, T), dtype=torch.float32, device=dev)
     rewards = torch.zeros((steps, E), dtype=torch.float64, device=dev)
     dones = torch.zeros((steps, E), dtype=torch.uint8, device=dev)
     act = torch.zeros((E, 2), dtype=torch.float64, device=dev)
+    infos = torch.zeros((steps, E), dtype=torch.uint8, device=dev)
     outs = env.alloc_step_outputs(("reward", "done", "info"))
     v_pref = float(env.get_state()["robot"][0, 7])
     gamma_bar = gamma ** (env.params.time_step * v_pref)
@@ -248,8 +296,9 @@ def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HU
         env.step_device(outs, robot_action=act, human_policy=human_policy, flags=_abi.FLAG_AUTO_RESET)
         rewards[t].copy_(outs["reward"])
         dones[t].copy_(outs["done"])
-    values, complete = il_value_targets(rewards, dones, gamma_bar)
-    keep = complete.reshape(-1)
+        infos[t].copy_(outs["info"])
+    values, keep = il_value_targets(rewards, dones, gamma_bar, infos)
+    keep = keep.reshape(-1)
     memory.push(states.reshape(steps * E, R, T)[keep], values.reshape(-1)[keep])
     return int(keep.sum()), int(dones.sum())
 
@@ -280,11 +329,13 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
     target = copy.deepcopy(model)                      # explorer.update_target_model (train.py:195)
     trainer.set_learning_rate(rl_learning_rate)
     policy = DeviceSarlPolicy(model.as_value_net(), actions, gamma)
+    t_max = int(round(env.params.time_limit / env.params.time_step)) + 2
+    store = EpisodeStore(env.E, t_max, env.R, env.T, dev)
     for it in range(train_iterations):
         eps = epsilon_start + (epsilon_end - epsilon_start) / epsilon_decay * it if it < epsilon_decay else epsilon_end
         mean_r = collect(env, policy, target.as_value_net(), memory, steps_per_iteration, gamma, epsilon=eps,
-                         generator=generator)
-        loss = trainer.optimize_batch(train_batches, generator)
+                         generator=generator, store=store)
+        loss = trainer.optimize_batch(train_batches, generator) if len(memory) else float("nan")
         if (it + 1) % target_update_interval == 0:
             target.load_state_dict(model.state_dict())
         hist["rl_loss"].append(loss)
@@ -292,3 +343,70 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
         if log:
             log("iteration %d: epsilon %.3f mean reward %.4f loss %.3e" % (it, eps, mean_r, loss))
     return hist
+
+
+def evaluate(env, decide, gamma, max_steps=None, human_policy=_abi.HUMAN_ORCA):
+    """Explorer.run_k_episodes on the `val` / `test` cases (explorer.py:33-131, :202-330), batched: one
+    episode per env of a freshly reset BatchedEnv (no auto-reset; an env that has ended is ignored from
+    then on).  decide(env) -> robot actions, float64 CUDA tensor [E, 2] (e.g. `lambda e:
+    policy.decide(e)[0]` with human_policy=EBC_HUMAN_CACHED: the decision's sweep has already worked out
+    the humans' velocities).  Returns the reference's compile_metrics() dictionary (same keys; the case
+    lists hold env indices) plus "num_episodes"."""
+    dev = torch.device("cuda", env.device)
+    E = env.E
+    dt = float(env.params.time_step)
+    limit = float(env.params.time_limit)
+    steps = int(max_steps or round(limit / dt) + 2)
+    outs = env.alloc_step_outputs(("reward", "done", "info", "dmin"))
+    v_pref = float(env.get_state()["robot"][0, 7])
+    gamma_bar = gamma ** (dt * v_pref)
+    dd = torch.tensor(list(env.params.discomfort_dist), dtype=torch.float64, device=dev)  # adult, bicycle, child
+    alive = torch.ones(E, dtype=torch.bool, device=dev)
+    final = torch.full((E,), -1, dtype=torch.int64, device=dev)
+    end_time = torch.zeros(E, dtype=torch.float64, device=dev)
+    cumulative = torch.zeros(E, dtype=torch.float64, device=dev)
+    too_close = torch.zeros((), dtype=torch.int64, device=dev)
+    min_sum = torch.zeros((), dtype=torch.float64, device=dev)
+    for t in range(steps):
+        actions = decide(env)
+        env.step_device(outs, robot_action=actions.contiguous(), human_policy=human_policy)
+        info = outs["info"].to(torch.int64)
+        cumulative += torch.where(alive, (gamma_bar ** t) * outs["reward"], torch.zeros_like(cumulative))
+        danger = alive & (info == _abi.INFO_DANGER)
+        dm = outs["dmin"]  # Danger.min_dist: the first type under its discomfort distance, child > bicycle > adult
+        md = torch.where(dm[:, 2] < dd[2], dm[:, 2], torch.where(dm[:, 1] < dd[1], dm[:, 1], dm[:, 0]))
+        too_close += danger.sum()
+        min_sum += torch.where(danger, md, torch.zeros_like(md)).sum()
+        ended = alive & outs["done"].bool()
+        final = torch.where(ended, info, final)
+        end_time = torch.where(ended, torch.where(info == _abi.INFO_TIMEOUT, torch.full_like(end_time, limit),
+                                                  torch.full_like(end_time, (t + 1) * dt)), end_time)
+        alive = alive & ~ended
+        if t % 8 == 7 and not bool(alive.any()):
+            break
+    final, end_time = final.cpu().numpy(), end_time.cpu().numpy()
+    if (final < 0).any():
+        raise ValueError("Invalid end signal from environment")  # explorer.py:80: every episode must end
+    n = float(E)
+    count = lambda code: int((final == code).sum())  # noqa: E731
+    cases = lambda code: [str(i) for i in np.nonzero(final == code)[0]]  # noqa: E731
+    ok = final == _abi.INFO_REACH_GOAL
+    num_step = end_time.sum() / dt
+    tc = int(too_close)
+    return {
+        "success_rate": count(_abi.INFO_REACH_GOAL) / n, "collision_rate": 0.0,
+        "collision_rate_adult": count(_abi.INFO_COLLISION_ADULT) / n,
+        "collision_rate_bicycle": count(_abi.INFO_COLLISION_BICYCLE) / n,
+        "collision_rate_child": count(_abi.INFO_COLLISION_CHILD) / n,
+        "collision_rate_obstacle": count(_abi.INFO_COLLISION_OBSTACLE) / n,
+        "success": count(_abi.INFO_REACH_GOAL), "collision": 0, "timeout": count(_abi.INFO_TIMEOUT),
+        "avg_nav_time": float(end_time[ok].mean()) if ok.any() else limit,
+        "total_reward:": float(cumulative.mean()),
+        "Frequency of being in danger": tc / num_step if num_step else None,
+        "average min separate distance in danger": float(min_sum) / tc if tc else 0,
+        "Collision cases:": [], "Collision Adult cases:": cases(_abi.INFO_COLLISION_ADULT),
+        "Collision Bicycle cases:": cases(_abi.INFO_COLLISION_BICYCLE),
+        "Collision Child cases:": cases(_abi.INFO_COLLISION_CHILD),
+        "Collision Obstacle cases:": cases(_abi.INFO_COLLISION_OBSTACLE),
+        "Timeout cases": cases(_abi.INFO_TIMEOUT), "num_episodes": E,
+    }

@@ -81,3 +81,43 @@ def test_sarl_decisions_gpu(name):
         assert int(outs["info"][0]) == int(z["info"][t]), t
         np.testing.assert_allclose(float(outs["reward"][0]), z["reward"][t], atol=1e-9)
     assert int(z["info"][-1]) == _abi.INFO_REACH_GOAL
+
+
+@pytest.mark.gpu
+def test_evaluate_reports_the_reference_metrics():
+    """Explorer.run_k_episodes' statistics (explorer.py:202-330) from one batched pass: the shipped SARL
+    weights on the golden episode's scene reach the goal in the golden episode's time, with its
+    discounted reward; and the imitation-learning demonstrator through the same function."""
+    from ebcsim.batched import BatchedEnv
+    from ebcsim.train import evaluate
+    z = load("sarl_a5_baseline")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    E = 6
+    b = batch_from_init(z, copies=E)
+    env = BatchedEnv(params, E, b.N, b.S)
+    env.reset(b)
+    env.use_torch_stream()
+    net = SarlValueNet.load(os.path.join(GOLDEN, "weights", meta["weights"]), device="cuda:0")
+    pol = DeviceSarlPolicy(net, z["action_space"], meta["gamma"])
+    m = evaluate(env, lambda e: pol.decide(e)[0], meta["gamma"], human_policy=_abi.HUMAN_CACHED)
+    T = len(z["action"])
+    assert m["success_rate"] == 1.0 and m["success"] == E and m["timeout"] == 0 and m["num_episodes"] == E
+    assert abs(m["avg_nav_time"] - T * params.time_step) <= 2 * params.time_step
+    gb = meta["gamma"] ** (params.time_step * float(b.robot[0, 7]))
+    ref_total = float(sum(gb ** t * r for t, r in enumerate(z["reward"])))
+    assert abs(m["total_reward:"] - ref_total) < 0.05
+    danger_steps = int((z["info"] == _abi.INFO_DANGER).sum())
+    if abs(m["avg_nav_time"] - T * params.time_step) < 1e-9:
+        np.testing.assert_allclose(m["Frequency of being in danger"], danger_steps / T, atol=1e-9)
+    # the demonstrator (robot on ORCA): every episode ends, the rates add up to one
+    env.reset(b)
+    act = torch.zeros((E, 2), dtype=torch.float64, device="cuda:0")
+
+    def demo(e):
+        e.robot_orca_device(act, 0.15)
+        return act
+    d = evaluate(env, demo, meta["gamma"])
+    total = (d["success_rate"] + d["collision_rate_adult"] + d["collision_rate_bicycle"] + d["collision_rate_child"]
+             + d["collision_rate_obstacle"] + d["timeout"] / E)
+    assert abs(total - 1.0) < 1e-12

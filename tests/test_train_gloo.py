@@ -192,3 +192,35 @@ def test_run_training_imitation_then_rl_on_device():
     assert hist["il_loss"] is not None and np.isfinite(hist["il_loss"])
     assert len(hist["rl_loss"]) == 3 and all(np.isfinite(v) for v in hist["rl_loss"])
     assert len(lines) == 4
+
+
+def test_episode_store_keeps_successes_and_collisions_only():
+    """explorer.py:82-92: pairs reach the memory when their episode ends, and only for ReachGoal or a
+    collision; a timeout's pairs are dropped; an unfinished episode keeps waiting."""
+    from ebcsim import _abi
+    from ebcsim.train import DeviceReplay, EpisodeStore, il_value_targets
+    E, R, T = 3, 2, 13
+    store, mem = EpisodeStore(E, 6, R, T, "cpu"), DeviceReplay(64, R, T, "cpu")
+    tag = lambda t: torch.full((E, R, T), float(t)) + torch.arange(E)[:, None, None] * 100.0  # noqa: E731
+    infos = [
+        [_abi.INFO_NOTHING, _abi.INFO_DANGER, _abi.INFO_NOTHING],
+        [_abi.INFO_REACH_GOAL, _abi.INFO_NOTHING, _abi.INFO_NOTHING],      # env 0 ends well after 2 steps
+        [_abi.INFO_NOTHING, _abi.INFO_TIMEOUT, _abi.INFO_NOTHING],         # env 1 times out after 3 steps
+        [_abi.INFO_COLLISION_CHILD, _abi.INFO_NOTHING, _abi.INFO_NOTHING],  # env 0's second episode: 2 steps
+    ]
+    pushed = []
+    for t, inf in enumerate(infos):
+        inf = torch.tensor(inf, dtype=torch.uint8)
+        done = ((inf == _abi.INFO_REACH_GOAL) | (inf >= _abi.INFO_COLLISION_OBSTACLE)).to(torch.uint8)
+        store.add(tag(t), torch.full((E,), float(t)))
+        pushed.append(store.end(done, inf, mem))
+    assert pushed == [0, 2, 0, 2] and len(mem) == 4
+    assert sorted(mem.states[:4, 0, 0].tolist()) == [0.0, 1.0, 2.0, 3.0]   # env 0's four steps, nobody else's
+    assert store.length.tolist() == [0, 1, 4]  # env 1 dropped its timeout and started over; env 2 still waiting
+    # the same filter in the windowed IL targets
+    r = torch.ones((4, E), dtype=torch.float64)
+    inf = torch.tensor(infos, dtype=torch.uint8)
+    done = ((inf == _abi.INFO_REACH_GOAL) | (inf >= _abi.INFO_COLLISION_OBSTACLE)).to(torch.uint8)
+    v, keep = il_value_targets(r, done, 0.5, inf)
+    assert keep[:, 0].all() and not keep[:, 1].any() and not keep[:, 2].any()
+    np.testing.assert_allclose(v[:, 0].numpy(), [1.5, 1.0, 1.5, 1.0])
