@@ -224,3 +224,35 @@ def test_episode_store_keeps_successes_and_collisions_only():
     v, keep = il_value_targets(r, done, 0.5, inf)
     assert keep[:, 0].all() and not keep[:, 1].any() and not keep[:, 2].any()
     np.testing.assert_allclose(v[:, 0].numpy(), [1.5, 1.0, 1.5, 1.0])
+
+
+def _epoch_worker(rank, world, port, ret):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from ebcsim.train import DataParallelTrainer, DeviceReplay, SarlModule
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = SarlModule(**DIMS)
+    n = 64 + 32 * rank  # shards of different sizes: every rank must take the same number of batches
+    x, y = _data(200 + rank, n)
+    mem = DeviceReplay(128, 5, 13, "cpu")
+    mem.push(x, 0.1 * y)
+    tr = DataParallelTrainer(model, mem, 32, "sgd", 0.01)
+    loss = tr.optimize_epoch(2, torch.Generator().manual_seed(rank))
+    ret[rank] = (loss, {k: v.detach().clone() for k, v in model.named_parameters()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_optimize_epoch_two_ranks_unequal_shards():
+    """The IL epochs under two gloo ranks with replay shards of different sizes: no rank waits for a
+    batch the other does not have, and the averaged gradients keep the replicas identical."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_epoch_worker, args=(2, 29900 + os.getpid() % 1000, ret), nprocs=2, join=True)
+    assert np.isfinite(ret[0][0]) and np.isfinite(ret[1][0])
+    for k, v in ret[0][1].items():
+        torch.testing.assert_close(ret[1][1][k], v, atol=1e-7, rtol=1e-6)
