@@ -153,19 +153,32 @@ struct OrcaLds {
   static constexpr int BYTES = DIST + 3 * GROUPS * Sh::LINES * 16;
 };
 
+// What an ORCA wave needs before it can issue its first load.  In the step launch these are the
+// leading kernel arguments, preloaded into scalar registers when the wave starts
+// (-amdgpu-kernarg-preload-count): role, human and tile address without a kernarg round trip.
+struct OrcaHot {
+  int E, N;
+  unsigned n_magic, n_shift;
+  const float4 *tile;
+  const int *n_humans;
+};
+__device__ __forceinline__ OrcaHot orca_hot(const DevState &s) {
+  return OrcaHot{s.E, s.N, s.n_magic, s.n_shift, s.tile, s.n_humans};
+}
+
 template <int GS>
-__device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s, bool h_ok, int e, int i,
+__device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s, const OrcaHot &hot, bool h_ok, int e, int i,
                                           unsigned char *scratch, float &ox, float &oy, bool &human_ok) {
   using L = OrcaLds<GS>;
   float *dist_lds = reinterpret_cast<float *>(scratch);
   float4 *lines_lds = reinterpret_cast<float4 *>(scratch + L::DIST);
   float4 *segs_lds = lines_lds + L::GROUPS * L::Sh::LINES;
   float4 *proj_lds = segs_lds + L::GROUPS * L::Sh::LINES;
-  const int N = s.N;
+  const int N = hot.N;
   const int lane = threadIdx.x & (EBC_WAVE - 1);
   const int group = lane / GS;
   const int j = lane - group * GS;  // "other" index in ob order
-  const int n = h_ok ? s.n_humans[e] : 0;
+  const int n = h_ok ? hot.n_humans[e] : 0;
   human_ok = h_ok && i < n;
   const size_t base = (size_t)e * N;
   // tile loads do not wait for n_humans: indices are clamped into the env's row, validity is
@@ -176,9 +189,9 @@ __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s,
   float posx = 0, posy = 0, velx = 0, vely = 0, radius = 0, maxSpeed = 0, prefx = 0, prefy = 0;
   float opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
   if (h_ok) {
-    const float4 a = s.tile[2 * ks], b = s.tile[2 * ks + 1];
-    const float4 c = s.tile[2 * ko];
-    orad = s.tile[2 * ko + 1].x;
+    const float4 a = hot.tile[2 * ks], b = hot.tile[2 * ks + 1];
+    const float4 c = hot.tile[2 * ko];
+    orad = hot.tile[2 * ko + 1].x;
     posx = a.x;
     posy = a.y;
     velx = a.z;
@@ -209,7 +222,7 @@ __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s,
 }
 
 // (env, slot) of flat human index h < E * N without the ~20-instruction integer divide
-__device__ __forceinline__ void split_human(const DevState &s, unsigned h, bool h_ok, int &e, int &i) {
+__device__ __forceinline__ void split_human(const OrcaHot &s, unsigned h, bool h_ok, int &e, int &i) {
   const unsigned N = (unsigned)s.N;
   const unsigned q = N > 1 ? (__umulhi(h, s.n_magic) >> s.n_shift) : h;
   e = h_ok ? (int)q : 0;
@@ -227,10 +240,11 @@ __global__ __launch_bounds__(EBC_WAVE) void orca_kernel(EbcParams p, DevState s)
   const unsigned N = (unsigned)s.N;
   const bool h_ok = group < HPW && h < (unsigned)s.E * N;  // lanes past HPW * GS idle
   int e, i;
-  split_human(s, h, h_ok, e, i);
+  const OrcaHot hot = orca_hot(s);
+  split_human(hot, h, h_ok, e, i);
   float ox, oy;
   bool human_ok;
-  orca_wave<GS>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
+  orca_wave<GS>(p, s, hot, h_ok, e, i, scratch, ox, oy, human_ok);
   if (h_ok && j == 0) {
     s.hact[(size_t)h * 2] = human_ok ? (double)ox : 0.0;  // getAgentVelocity -> Python float
     s.hact[(size_t)h * 2 + 1] = human_ok ? (double)oy : 0.0;
@@ -918,26 +932,27 @@ __device__ __forceinline__ void sreg(const Tp &x) {
 
 // ---- ORCA
 template <int GS>
-__device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s, unsigned char *scratch,
-                                          unsigned block, bool rows, int lane) {
-  sreg(s.E); sreg(s.N); sreg(s.n_magic); sreg(s.n_shift); sreg(s.n_humans); sreg(s.tile); sreg(s.robot);
-  sreg(s.vel_state); sreg(s.vel_rows); sreg(s.range_sq); sreg(s.inv_time_horizon); sreg(s.inv_time_step);
+__device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s, const OrcaHot &hot,
+                                          unsigned long long *vel_state, unsigned long long *vel_rows,
+                                          unsigned char *scratch, unsigned block, bool rows, int lane) {
+  // `hot`, vel_state, vel_rows: preloaded kernel arguments; the rest is asked for now, all at once
+  sreg(s.robot); sreg(s.range_sq); sreg(s.inv_time_horizon); sreg(s.inv_time_step);
   sreg(p.robot_visible); sreg(p.orca_max_neighbors); sreg(p.orca_safety_space);
   constexpr int HPW = EBC_WAVE / GS;
   const int group = lane / GS, j = lane - group * GS;
   // 32-bit index math (E * N < 2^31 is checked at create)
   const unsigned hh = block * HPW + group;
-  const bool h_ok = group < HPW && hh < (unsigned)s.E * (unsigned)s.N;  // lanes past HPW * GS idle
+  const bool h_ok = group < HPW && hh < (unsigned)hot.E * (unsigned)hot.N;  // lanes past HPW * GS idle
   int e, i;
-  split_human(s, hh, h_ok, e, i);
+  split_human(hot, hh, h_ok, e, i);
   float ox, oy;
   bool human_ok;
-  orca_wave<GS>(p, s, h_ok, e, i, scratch, ox, oy, human_ok);
+  orca_wave<GS>(p, s, hot, h_ok, e, i, scratch, ox, oy, human_ok);
   if (h_ok && j == 0) {
     unsigned long long v = human_ok ? ((unsigned long long)__float_as_uint(oy) << 32) | __float_as_uint(ox) : 0ull;
     if (v == EBC_SLOT_EMPTY) v = 0x7FC000007FC00000ull;  // not an arithmetic result; keeps the protocol total
-    mailbox_put(s.vel_state + hh, v);
-    if (rows) mailbox_put(s.vel_rows + hh, v);  // a box nobody empties would hold a stale velocity
+    mailbox_put(vel_state + hh, v);
+    if (rows) mailbox_put(vel_rows + hh, v);  // a box nobody empties would hold a stale velocity
   }
 }
 
@@ -1199,7 +1214,12 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
 #define EBC_STEP_WPB 1
 #endif
 template <int GS, int T>
-__global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void orca_step_kernel(EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
+__global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void orca_step_kernel(
+    // 14 dwords the wave finds in scalar registers when it starts (kernarg preload): its role and, for
+    // an ORCA wave, everything up to its first vector load
+    unsigned env_blocks, unsigned orca_blocks, int hot_E, int hot_N, unsigned hot_magic, unsigned hot_shift,
+    const float4 *hot_tile, const int *hot_n_humans, unsigned long long *hot_vel_state, unsigned long long *hot_vel_rows,
+    EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
   const WaveTrace wt(2);
   constexpr size_t LDS = ((sizeof(RoleLds) > (size_t)OrcaLds<GS>::BYTES ? sizeof(RoleLds) : (size_t)OrcaLds<GS>::BYTES) + 15) / 16 * 16;
   __shared__ __align__(16) unsigned char lds_all[EBC_STEP_WPB][LDS];
@@ -1211,17 +1231,18 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
 #ifndef EBC_ROLE_MASK  // register-budget experiments: compile a subset of the roles
 #define EBC_ROLE_MASK 15
 #endif
-  if (b < g.env_blocks) {
+  if (b < env_blocks) {
     __builtin_amdgcn_s_setprio(3);  // the long dependent chain of the launch
     if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, g.epoch, lane);
     return;
   }
-  b -= g.env_blocks;
-  if (b < g.orca_blocks) {
-    if (EBC_ROLE_MASK & 2) orca_role<GS>(p_in, s_in, lds, b, g.rows_blocks != 0, lane);
+  b -= env_blocks;
+  if (b < orca_blocks) {
+    const OrcaHot hot{hot_E, hot_N, hot_magic, hot_shift, hot_tile, hot_n_humans};
+    if (EBC_ROLE_MASK & 2) orca_role<GS>(p_in, s_in, hot, hot_vel_state, hot_vel_rows, lds, b, g.rows_blocks != 0, lane);
     return;
   }
-  b -= g.orca_blocks;
+  b -= orca_blocks;
   if (b < g.rows_blocks) {
     if (EBC_ROLE_MASK & 4) rows_role<T>(p_in, s_in, io_in, L, b, g.rows_epw, g.epoch, lane);
     return;

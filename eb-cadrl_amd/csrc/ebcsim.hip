@@ -165,9 +165,13 @@ int launch_service(Handle *h, const StepIO &io) {
 template <int GS>
 int launch_orca_step_gs(Handle *h, const StepIO &io, unsigned blocks, const ebc::StepGrid &g) {
   if (h->T == 17)
-    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 17>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream, h->p, h->s, io, g);
+    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 17>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream,
+                       g.env_blocks, g.orca_blocks, h->s.E, h->s.N, h->s.n_magic, h->s.n_shift, (const float4 *)h->s.tile,
+                       (const int *)h->s.n_humans, h->s.vel_state, h->s.vel_rows, h->p, h->s, io, g);
   else
-    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 13>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream, h->p, h->s, io, g);
+    hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 13>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream,
+                       g.env_blocks, g.orca_blocks, h->s.E, h->s.N, h->s.n_magic, h->s.n_shift, (const float4 *)h->s.tile,
+                       (const int *)h->s.n_humans, h->s.vel_state, h->s.vel_rows, h->p, h->s, io, g);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
