@@ -109,8 +109,13 @@ class SarlValueNet(object):
                     st[0][0].shape[1] <= 224 and st[1][0].shape[0] <= 224 for st in stacks):
                 idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
                 try:
-                    self._native = (_NativeMlp2(self.mlp1, idx), _NativeMlp2(self.mlp2, idx),
-                                    _NativeMlp2(att, idx, final=self.attention[2]))
+                    blocks = [_NativeMlp2(self.mlp1, idx), _NativeMlp2(self.mlp2, idx),
+                              _NativeMlp2(att, idx, final=self.attention[2])]
+                    # mlp3's first two layers (the joint vector's widest ones) as a fourth block; its tail
+                    # (the reference's 200 -> 200 -> 1) stays with torch
+                    if (len(self.mlp3) >= 3 and self.mlp3[0][0].shape[1] <= 224 and self.mlp3[1][0].shape[0] <= 224):
+                        blocks.append(_NativeMlp2(self.mlp3[:2], idx))
+                    self._native = tuple(blocks)
                 except Exception:  # an unsupported shape: stay on the torch path
                     self._native = ()
             else:
@@ -166,6 +171,8 @@ class SarlValueNet(object):
             e = e * valid
         w = (e / e.sum(dim=1, keepdim=True)).unsqueeze(2)
         joint = torch.cat([self_state, (w * feat).sum(dim=1)], dim=1)
+        if nat is not None and len(nat) > 3:
+            return _mlp(nat[3](joint, True), self.mlp3[2:], False).squeeze(1).to(torch.float32)
         return _mlp(joint, self.mlp3, False).squeeze(1).to(torch.float32)
 
 
