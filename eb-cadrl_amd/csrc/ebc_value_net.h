@@ -261,4 +261,96 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
   }
 }
 
+// ---- the per-pair glue of the value network (rl/policy/sarl.py:52-78), HBM-bound ------------------
+// A "pair" = one (env, action) joint state = R consecutive rows, of which the first n_valid[b] exist
+// (NULL: all R).  One wave per pair; lanes walk the feature dimension in 16-byte vectors, rows serially.
+
+// g[b] = mean over the pair's rows of h[b][r][:]  (sarl.py:56-58: the global state), one pass over h.
+__global__ __launch_bounds__(256) void pair_mean_kernel(const float *h, const long long *n_valid, int B, int R, int H,
+                                                        float *g) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const int nv = n_valid ? (int)n_valid[b] : R;
+  const float denom = (float)(nv < 1 ? 1 : nv);
+  const float *base = h + (size_t)b * R * H;
+  for (int c = lane * 4; c < H; c += 256) {
+    if (c + 3 < H) {
+      float4 acc = make_float4(0, 0, 0, 0);
+      for (int r = 0; r < nv; ++r) {
+        const float4 v = *reinterpret_cast<const float4 *>(base + (size_t)r * H + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4 *>(g + (size_t)b * H + c) = make_float4(acc.x / denom, acc.y / denom, acc.z / denom, acc.w / denom);
+    } else {
+      for (int k = c; k < H; ++k) {
+        float acc = 0.0f;
+        for (int r = 0; r < nv; ++r) acc += base[(size_t)r * H + k];
+        g[(size_t)b * H + k] = acc / denom;
+      }
+    }
+  }
+}
+
+// out[b] = sum_r w_r feat[b][r][:],  w = the reference's masked softmax of the pair's scores
+// (sarl.py:69-72: exp(s) * (s != 0), normalised), rows past n_valid[b] excluded; one pass over feat.
+__global__ __launch_bounds__(256) void pair_attend_kernel(const float *scores, const float *feat, const long long *n_valid,
+                                                          int B, int R, int F, float *out) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const int nv = n_valid ? (int)n_valid[b] : R;
+  // the R <= 64 scores of the pair, one per lane; their sum across the wave
+  float e = 0.0f;
+  float total = 0.0f;
+  for (int r0 = 0; r0 < R; r0 += 64) {  // R > 64: several passes for the normaliser
+    const int r = r0 + lane;
+    float er = 0.0f;
+    if (r < nv) {
+      const float sc = scores[(size_t)b * R + r];
+      er = sc != 0.0f ? expf(sc) : 0.0f;
+    }
+    float t = er;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    total += t;
+    if (r0 == 0) e = er;
+  }
+  // one 16-byte chunk of the features per lane (F <= 256); the row loop is wave-uniform, so the
+  // broadcast of a row's weight reads active lanes only
+  const float *base = feat + (size_t)b * R * F;
+  const int c = lane * 4;
+  const bool act = c < F, vec = c + 3 < F;
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (int r = 0; r < nv; ++r) {
+    float er;
+    if (r < 64) {
+      er = __shfl(e, r, 64);
+    } else {
+      const float sc = scores[(size_t)b * R + r];
+      er = sc != 0.0f ? expf(sc) : 0.0f;
+    }
+    const float w = er / total;
+    if (act) {
+      const float *row = base + (size_t)r * F + c;
+      if (vec) {
+        const float4 v = *reinterpret_cast<const float4 *>(row);
+        acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+      } else {
+        acc.x += w * row[0];
+        if (c + 1 < F) acc.y += w * row[1];
+        if (c + 2 < F) acc.z += w * row[2];
+      }
+    }
+  }
+  if (act) {
+    float *o = out + (size_t)b * F + c;
+    if (vec) {
+      *reinterpret_cast<float4 *>(o) = acc;
+    } else {
+      o[0] = acc.x;
+      if (c + 1 < F) o[1] = acc.y;
+      if (c + 2 < F) o[2] = acc.z;
+    }
+  }
+}
+
 }  // namespace ebc

@@ -983,6 +983,30 @@ int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_ou
   }
 }
 
+int ebc_pair_mean(void *stream, const float *h, const long long *n_valid, int B, int R, int H, float *g) {
+  if (!h || !g || B < 0 || R <= 0 || H <= 0) return fail(EBC_ERR_INVALID, "pair_mean arguments");
+  if (B == 0) return EBC_OK;
+  if (((size_t)h | (size_t)g) & 15 || (H & 3)) {
+    if (H & 3) return fail(EBC_ERR_UNSUPPORTED, "pair_mean: H must be a multiple of 4");
+    return fail(EBC_ERR_INVALID, "pair_mean: 16-byte aligned buffers");
+  }
+  hipLaunchKernelGGL(ebc::pair_mean_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, n_valid, B, R, H, g);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+int ebc_pair_attend(void *stream, const float *scores, const float *feat, const long long *n_valid, int B, int R, int F,
+                    float *out) {
+  if (!scores || !feat || !out || B < 0 || R <= 0 || F <= 0) return fail(EBC_ERR_INVALID, "pair_attend arguments");
+  if (B == 0) return EBC_OK;
+  if ((F & 3) || F > 256) return fail(EBC_ERR_UNSUPPORTED, "pair_attend: F must be a multiple of 4, at most 256");
+  if (((size_t)feat | (size_t)out) & 15) return fail(EBC_ERR_INVALID, "pair_attend: 16-byte aligned buffers");
+  hipLaunchKernelGGL(ebc::pair_attend_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, feat,
+                     n_valid, B, R, F, out);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
 int ebc_mlp2_destroy(void *mlp) {
   Mlp2 *m = (Mlp2 *)mlp;
   if (!m) return EBC_OK;

@@ -36,6 +36,8 @@ SYMBOLS = {
     "ebc_mlp2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p]),
     "ebc_mlp2_destroy": (C.c_int, [C.c_void_p]),
+    "ebc_pair_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ebc_pair_attend": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 

@@ -122,6 +122,28 @@ class SarlValueNet(object):
                 self._native = ()
         return getattr(self, "_native", ()) or None
 
+    @staticmethod
+    def _pair_mean(h1, nv64, B, R):
+        """sarl.py:56-58 in one pass over h1 (libebcsim ebc_pair_mean)."""
+        from . import _capi
+        h1 = h1.contiguous()
+        g = torch.empty((B, h1.shape[1]), dtype=torch.float32, device=h1.device)
+        _capi.check(_capi.lib().ebc_pair_mean(torch.cuda.current_stream(h1.device).cuda_stream, h1.data_ptr(),
+                                              None if nv64 is None else nv64.data_ptr(), B, R, int(h1.shape[1]),
+                                              g.data_ptr()))
+        return g
+
+    @staticmethod
+    def _pair_attend(scores, feat, nv64, B, R):
+        """sarl.py:69-76 in one pass over the features (libebcsim ebc_pair_attend)."""
+        from . import _capi
+        scores, feat = scores.contiguous(), feat.contiguous()
+        out = torch.empty((B, feat.shape[2]), dtype=torch.float32, device=feat.device)
+        _capi.check(_capi.lib().ebc_pair_attend(torch.cuda.current_stream(feat.device).cuda_stream, scores.data_ptr(),
+                                                feat.data_ptr(), None if nv64 is None else nv64.data_ptr(), B, R,
+                                                int(feat.shape[2]), out.data_ptr()))
+        return out
+
     @classmethod
     def load(cls, path, device="cpu", **kw):
         return cls(torch.load(path, map_location="cpu"), device=device, **kw)
@@ -142,17 +164,23 @@ class SarlValueNet(object):
         else:
             h1 = _mlp(rows.reshape(B * R, T), self.mlp1, True)
             feat = _mlp(h1, self.mlp2, False).view(B, R, -1)
-        if n_valid is None:
+        fused = (nat is not None and h1.shape[1] % 4 == 0 and feat.shape[2] % 4 == 0
+                 and feat.shape[2] <= 256)  # the pair glue as two HIP kernels
+        nv64 = None if n_valid is None else n_valid.to(torch.int64).contiguous()
+        if fused or n_valid is None:
             valid = None
             denom = float(R)
         else:
             valid = (torch.arange(R, device=rows.device)[None, :] < n_valid[:, None])
             denom = n_valid.to(rows.dtype).clamp(min=1)[:, None, None]
         if self.with_global_state:
-            h1v = h1.view(B, R, -1)
-            if valid is not None:
-                h1v = h1v * valid[:, :, None]
-            g = h1v.sum(1) / (denom if isinstance(denom, float) else denom[:, 0, :])  # [B, H]: mean of the pair's rows
+            if fused:
+                g = self._pair_mean(h1, nv64, B, R)
+            else:
+                h1v = h1.view(B, R, -1)
+                if valid is not None:
+                    h1v = h1v * valid[:, :, None]
+                g = h1v.sum(1) / (denom if isinstance(denom, float) else denom[:, 0, :])  # [B, H]: mean of the pair's rows
             # attention layer 1 on cat([h1, g]) without building the concatenation: the g half of the
             # weight acts once per pair, its result is added to every row of the pair
             H = h1.shape[1]
@@ -166,11 +194,15 @@ class SarlValueNet(object):
                 scores = _mlp(a1, self.attention[1:], False).view(B, R)
         else:
             scores = _mlp(h1, self.attention, False).view(B, R)
-        e = torch.exp(scores) * (scores != 0).to(scores.dtype)  # the reference's masked softmax (sarl.py:69-70)
-        if valid is not None:
-            e = e * valid
-        w = (e / e.sum(dim=1, keepdim=True)).unsqueeze(2)
-        joint = torch.cat([self_state, (w * feat).sum(dim=1)], dim=1)
+        if fused:
+            attended = self._pair_attend(scores, feat, nv64, B, R)
+        else:
+            e = torch.exp(scores) * (scores != 0).to(scores.dtype)  # the reference's masked softmax (sarl.py:69-70)
+            if valid is not None:
+                e = e * valid
+            w = (e / e.sum(dim=1, keepdim=True)).unsqueeze(2)
+            attended = (w * feat).sum(dim=1)
+        joint = torch.cat([self_state, attended], dim=1)
         if nat is not None and len(nat) > 3:
             return _mlp(nat[3](joint, True), self.mlp3[2:], False).squeeze(1).to(torch.float32)
         return _mlp(joint, self.mlp3, False).squeeze(1).to(torch.float32)
@@ -179,7 +211,7 @@ class SarlValueNet(object):
 class DeviceSarlPolicy(object):
     """Greedy SARL decisions for a whole BatchedEnv (phase "test": no epsilon draw)."""
 
-    def __init__(self, net, actions, gamma, chunk_rows=1 << 19):
+    def __init__(self, net, actions, gamma, chunk_rows=1 << 21):
         self.net = net
         self.actions_np = np.ascontiguousarray(actions, dtype=np.float64)
         self.gamma = float(gamma)

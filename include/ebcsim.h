@@ -280,6 +280,16 @@ int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_ou
                      int group_rows, float *y);
 int ebc_mlp2_destroy(void *mlp);
 
+/* The per-pair glue of ValueNetwork.forward between those blocks (rl/policy/sarl.py:52-78), one pass over
+ * the activations each.  A pair = one joint state = R consecutive rows, the first n_valid[b] of which exist
+ * (device int64 [B]; NULL = all R).  Device pointers, 16-byte aligned; H and F multiples of 4, F <= 256.
+ *   ebc_pair_mean:   g [B][H] = mean over the pair's rows of h [B*R][H]            (sarl.py:56-58)
+ *   ebc_pair_attend: out [B][F] = sum_r softmax'(scores)[b][r] feat [B*R][F], softmax' = exp(s) (s != 0)
+ *                    normalised over the pair's rows                                 (sarl.py:69-76) */
+int ebc_pair_mean(void *stream, const float *h, const long long *n_valid, int B, int R, int H, float *g);
+int ebc_pair_attend(void *stream, const float *scores, const float *feat, const long long *n_valid, int B, int R,
+                    int F, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,3 +78,32 @@ def test_mlp2_attention_form(K0, H, O, R, B):
     err = np.abs(yd.cpu().numpy() - ref).max()
     assert err <= 4e-5 * max(np.abs(ref).max(), 1.0), err
     _capi.check(L.ebc_mlp2_destroy(h))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,R,H,F,ragged", [(257, 18, 200, 100, True), (64, 5, 100, 52, False), (33, 70, 8, 4, True)])
+def test_pair_glue_matches_torch(B, R, H, F, ragged):
+    """ebc_pair_mean / ebc_pair_attend against the torch float32 form of sarl.py:56-58 and :69-76
+    (masked mean over the pair's rows; exp(s) * (s != 0) normalised, weighted feature sum), ragged
+    row counts, exact-zero scores, more rows than lanes."""
+    import torch
+    from ebcsim.sarl import SarlValueNet
+    g = torch.Generator().manual_seed(B * 31 + R)
+    h = torch.randn(B * R, H, generator=g).cuda()
+    feat = torch.randn(B, R, F, generator=g).cuda()
+    scores = torch.randn(B, R, generator=g)
+    scores[torch.rand(B, R, generator=g) < 0.1] = 0.0   # the reference treats a zero score as "no row"
+    scores = scores.cuda()
+    nv = None
+    if ragged:
+        nv = torch.randint(1, R + 1, (B,), generator=g).cuda()
+    valid = torch.ones(B, R, device="cuda") if nv is None else (torch.arange(R, device="cuda")[None, :] < nv[:, None]).float()
+    denom = float(R) if nv is None else nv.float()[:, None]
+    ref_g = (h.view(B, R, H) * valid[:, :, None]).sum(1) / denom
+    e = torch.exp(scores) * (scores != 0).float() * valid
+    ref_o = ((e / e.sum(1, keepdim=True)).unsqueeze(2) * feat).sum(1)
+    got_g = SarlValueNet._pair_mean(h, nv, B, R)
+    got_o = SarlValueNet._pair_attend(scores, feat, nv, B, R)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(got_g, ref_g, atol=2e-6, rtol=1e-5)
+    torch.testing.assert_close(got_o, ref_o, atol=2e-6, rtol=1e-5)
