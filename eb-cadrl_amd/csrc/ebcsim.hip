@@ -896,8 +896,10 @@ int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool ac
 template <int TI, int TO>
 int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
   // NW waves per workgroup, a 32-row tile each; the weights of one hidden tile twice in LDS
-  constexpr bool fits256 = (TI + TO) * 16 + 64 <= 256;  // fragments, accumulators, working set (as the kernel's launch bounds)
-  constexpr int NW = (fits256 && 2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4;
+  // 8 also where the tiles want more than the 256 registers two waves per SIMD leave each (7 + 7 tiles:
+  // a few spilled registers): measured, two waves per SIMD beat one with all its registers
+  // (attention block 791 -> 692 us per 0.5 M rows; 5.60 -> 5.17 ms per 1024-env decision batch)
+  constexpr int NW = (2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4;
   const size_t lds = 2 * (size_t)(TI + TO) * 2 * 2 * 64 * 16 + (size_t)m->L1.out_tiles * 32 * 4;
   static size_t raised = 0;  // more than the 64 KB a launch gets by default
   if (lds > 65536 && lds > raised) {
