@@ -233,10 +233,15 @@ class DeviceSarlPolicy(object):
 
     def decide(self, env, human_policy=_abi.HUMAN_ORCA):
         """env: BatchedEnv on this net's device.  Returns (actions [E, 2] float64 CUDA tensor,
-        values [E, A]); the human velocities stay cached for a following EBC_HUMAN_CACHED step."""
+        values [E, A]); the human velocities stay cached for a following EBC_HUMAN_CACHED step.
+        The sweep's buffers and the envs' row counts are taken when an env batch is first seen (a
+        different batch re-allocates them): a scene pool whose scenes differ in their number of humans
+        or static rows needs a fresh policy object (or `_bufs = None`) after the counts change."""
         dev = self.net.device
         A = len(self.actions_np)
-        if self._bufs is None:
+        key = (id(env), env.E, env.R, env.T)
+        if self._bufs is None or getattr(self, "_env_key", None) != key:  # buffers are sized for ONE env batch
+            self._env_key = key
             self._acts = torch.tensor(self.actions_np, dtype=torch.float64, device=dev)
             self._bufs = env.alloc_lookahead_outputs(A, ("reward", "rows_rotated"))
             st = env.get_state()

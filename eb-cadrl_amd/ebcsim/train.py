@@ -306,32 +306,64 @@ def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HU
 def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learning_rate=0.01, il_safety_space=0.15,
                  rl_learning_rate=0.001, train_iterations=0, steps_per_iteration=1, train_batches=100,
                  batch_size=100, capacity=100000, epsilon_start=0.5, epsilon_end=0.1, epsilon_decay=4000,
-                 target_update_interval=50, optimizer_algorithm="sgd", generator=None, log=None):
+                 target_update_interval=50, optimizer_algorithm="sgd", generator=None, log=None,
+                 output_dir=None, checkpoint_interval=0, evaluation_interval=0, val_env=None, val_scenes=None,
+                 rank=0):
     """The schedule of rl/train.py:99-260 on one rank's env slice (every rank calls it; gradients are
     averaged over ranks inside the trainer): imitation learning with the robot on ORCA
     (`il_steps` steps of every env, then `il_epochs` passes over the memory), then `train_iterations`
     rounds of [epsilon-greedy rollout of `steps_per_iteration` decisions per env -> `train_batches`
     optimizer steps], the target network refreshed every `target_update_interval` rounds, epsilon
     decayed linearly over `epsilon_decay` rounds (train.py:211-218).  env: BatchedEnv with auto-reset
-    semantics, on the model's device.  Returns a dict of what happened."""
+    semantics, on the model's device.  Returns a dict of what happened.
+    output_dir: the reference's weight files, in its state_dict layout (they load into its ValueNetwork):
+    `il_model.pth` after imitation learning — found there, it is loaded and the stage skipped
+    (train.py:113-116) — and `rl_model_<round>.pth` every `checkpoint_interval` rounds and at the end
+    (train.py:146-150, :262-270); written by `rank` 0 only.  evaluation_interval: every so many rounds the
+    greedy policy runs `val_scenes` (a SceneBatch) on `val_env` once through (train.py:222-236, `evaluate`);
+    the metrics go to hist["val"]."""
+    import os
     from .sarl import DeviceSarlPolicy
     dev = next(model.parameters()).device
     memory = DeviceReplay(capacity, env.R, env.T, dev)
     trainer = DataParallelTrainer(model, memory, batch_size, optimizer_algorithm, il_learning_rate)
-    hist = {"il_stored": 0, "il_episodes": 0, "il_loss": None, "rl_loss": [], "mean_reward": []}
+    hist = {"il_stored": 0, "il_episodes": 0, "il_loss": None, "rl_loss": [], "mean_reward": [], "val": [],
+            "il_loaded": False}
+    il_file = os.path.join(output_dir, "il_model.pth") if output_dir else None
+
+    def save(path):
+        if rank == 0 and output_dir:
+            os.makedirs(output_dir, exist_ok=True)
+            torch.save({k: v.cpu() for k, v in model.reference_state_dict().items()}, path)
+    if il_file and os.path.exists(il_file):
+        model.load_reference_state_dict(torch.load(il_file, map_location="cpu"))
+        hist["il_loaded"] = True
+        il_steps = 0
+        if log:
+            log("imitation learning: weights loaded from %s" % il_file)
     if il_steps > 0:
         hist["il_stored"], hist["il_episodes"] = collect_il(env, memory, il_steps, gamma, il_safety_space)
         if len(memory) and il_epochs > 0:
             hist["il_loss"] = trainer.optimize_epoch(il_epochs, generator)
+        if il_file:
+            save(il_file)
         if log:
             log("imitation learning: %d states of %d episodes, loss %s" % (hist["il_stored"], hist["il_episodes"], hist["il_loss"]))
     import copy
     target = copy.deepcopy(model)                      # explorer.update_target_model (train.py:195)
     trainer.set_learning_rate(rl_learning_rate)
     policy = DeviceSarlPolicy(model.as_value_net(), actions, gamma)
+    val_policy = DeviceSarlPolicy(policy.net, actions, gamma)  # same network, its own look-ahead buffers (val_env's size)
     t_max = int(round(env.params.time_limit / env.params.time_step)) + 2
     store = EpisodeStore(env.E, t_max, env.R, env.T, dev)
     for it in range(train_iterations):
+        if evaluation_interval and val_env is not None and val_scenes is not None and it % evaluation_interval == 0:
+            val_env.reset(val_scenes)
+            hist["val"].append((it, evaluate(val_env, lambda e: val_policy.decide(e)[0], gamma, human_policy=_abi.HUMAN_CACHED)))
+            if log:
+                m = hist["val"][-1][1]
+                log("VAL   in round %d has success rate: %.2f, nav time: %.2f, total reward: %.4f" % (
+                    it, m["success_rate"], m["avg_nav_time"], m["total_reward:"]))
         eps = epsilon_start + (epsilon_end - epsilon_start) / epsilon_decay * it if it < epsilon_decay else epsilon_end
         mean_r = collect(env, policy, target.as_value_net(), memory, steps_per_iteration, gamma, epsilon=eps,
                          generator=generator, store=store)
@@ -340,8 +372,12 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
             target.load_state_dict(model.state_dict())
         hist["rl_loss"].append(loss)
         hist["mean_reward"].append(mean_r)
+        if checkpoint_interval and (it + 1) % checkpoint_interval == 0:
+            save(os.path.join(output_dir or ".", "rl_model_%d.pth" % (it + 1)))
         if log:
             log("iteration %d: epsilon %.3f mean reward %.4f loss %.3e" % (it, eps, mean_r, loss))
+    if train_iterations:
+        save(os.path.join(output_dir or ".", "rl_model_%d.pth" % train_iterations))
     return hist
 
 

@@ -194,6 +194,43 @@ def test_run_training_imitation_then_rl_on_device():
     assert len(lines) == 4
 
 
+@pytest.mark.gpu
+def test_run_training_checkpoints_and_validation(tmp_path):
+    """The reference's weight files (il_model.pth, rl_model_<n>.pth, its state_dict layout), the IL stage
+    skipped when il_model.pth is there (train.py:113-116), validation rounds through evaluate()."""
+    import json
+    from helpers import batch_from_init, load, params_of
+    from ebcsim.batched import BatchedEnv
+    from ebcsim.sarl import SarlValueNet
+    from ebcsim.train import SarlModule, run_training
+    z = load("sarl_a5_baseline")
+    meta = json.loads(str(z["meta"]))
+    E = 32
+    b = batch_from_init(z, copies=E)
+    env = BatchedEnv(params_of(z), E, b.N, b.S)
+    env.reset(b)
+    env.use_torch_stream()
+    val_env = BatchedEnv(params_of(z), 4, b.N, b.S)
+    val_env.use_torch_stream()
+    val_scenes = batch_from_init(z, copies=4)
+    out = str(tmp_path / "out")
+    kw = dict(il_learning_rate=0.01, train_iterations=2, steps_per_iteration=3, train_batches=3, capacity=20000,
+              epsilon_decay=2, target_update_interval=1, output_dir=out, checkpoint_interval=1, evaluation_interval=1,
+              val_env=val_env, val_scenes=val_scenes)
+    model = SarlModule(**DIMS).to("cuda:0")
+    h1 = run_training(env, model, z["action_space"], meta["gamma"], il_steps=120, il_epochs=1, **kw)
+    assert not h1["il_loaded"] and sorted(os.listdir(out)) == ["il_model.pth", "rl_model_1.pth", "rl_model_2.pth"]
+    assert len(h1["val"]) == 2 and h1["val"][0][1]["num_episodes"] == 4
+    sd = torch.load(os.path.join(out, "rl_model_2.pth"), map_location="cpu")
+    assert "mlp1.0.weight" in sd and "attention.4.bias" in sd      # the reference's ValueNetwork keys
+    net = SarlValueNet(sd)                                          # loads like a shipped .pth
+    torch.testing.assert_close(net.forward(torch.zeros(1, b.N + b.S, 13)), model.cpu()(torch.zeros(1, b.N + b.S, 13)))
+    model2 = SarlModule(**DIMS).to("cuda:0")
+    env.reset(b)
+    h2 = run_training(env, model2, z["action_space"], meta["gamma"], il_steps=120, il_epochs=1, **kw)
+    assert h2["il_loaded"] and h2["il_stored"] == 0
+
+
 def test_episode_store_keeps_successes_and_collisions_only():
     """explorer.py:82-92: pairs reach the memory when their episode ends, and only for ReachGoal or a
     collision; a timeout's pairs are dropped; an unfinished episode keeps waiting."""
