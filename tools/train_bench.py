@@ -67,12 +67,21 @@ def main():
     del mem
     env.reset(batch)
     t0 = sync()
+    marks = []
     hist = run_training(env, model, space, 0.9, il_steps=args.il_steps, il_epochs=args.il_epochs, train_iterations=args.iterations,
                         steps_per_iteration=args.steps_per_iteration, train_batches=args.train_batches,
-                        batch_size=args.batch_size, capacity=max(100000, args.il_steps * args.envs), generator=g)
+                        batch_size=args.batch_size, capacity=max(100000, args.il_steps * args.envs), generator=g,
+                        log=lambda line: marks.append((line.split(":")[0], sync())))
     t1 = sync()
     times["schedule_s"] = t1 - t0
     decisions = args.iterations * args.steps_per_iteration * args.envs * world
+    rl = [t for name, t in marks if name.startswith("iteration")]
+    if len(rl) >= 2:  # the RL rounds after the first (its first decision allocates the sweep's buffers)
+        per_round = (rl[-1] - rl[0]) / (len(rl) - 1)
+        times["rl_round_s"] = per_round
+        times["rl_decisions_per_s"] = args.steps_per_iteration * args.envs * world / per_round
+        times["rl_round"] = "%d decisions per env + %d optimizer steps of batch %d" % (
+            args.steps_per_iteration, args.train_batches, args.batch_size)
     if rank == 0:
         print(json.dumps({"world": world, "envs_per_gpu": args.envs, "humans": int(batch.N), "il_states_stored": stored,
                           "il_episodes": episodes, "il_loss": hist["il_loss"], "rl_loss": hist["rl_loss"],
