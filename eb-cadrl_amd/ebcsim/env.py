@@ -62,6 +62,9 @@ class EntityBasedCollisionAvoidance(object):
         self.action_values = None
         self.attention_weights = None
         self.phase = None
+        self._humans_cached = False
+        self.backend_calls = 0      # launches-level calls through the C ABI (tests count them)
+        self.orca_evaluations = 0   # of which evaluated ORCA for the humans
 
     # ---------------------------------------------------------------- configuration
     def configure(self, config):
@@ -97,9 +100,12 @@ class EntityBasedCollisionAvoidance(object):
 
     def _ensure_backend(self, n_humans, n_static):
         kin = self.robot.kinematics or "holonomic"
-        key = (n_humans, n_static, kin)
+        # the width of a rotated row follows the robot's policy (rl/policy/sarl.py:103-110)
+        typed = bool(getattr(self.robot.policy, "with_agent_type", False))
+        key = (n_humans, n_static, kin, typed)
         if key != self._backend_key:
             params = ebc_config.params_from_config(self.config, robot_kinematics=kin)
+            params.with_agent_type = int(typed)
             if self._backend is not None and hasattr(self._backend, "close"):
                 self._backend.close()
             if self._factory is not None:
@@ -181,6 +187,7 @@ class EntityBasedCollisionAvoidance(object):
         batch = ebc_scene.SceneBatch.from_scenes([scene])
         backend = self._ensure_backend(batch.N, batch.S)
         backend.reset(batch)
+        self._humans_cached = False
 
         self.states = list()
         self.local_maps_angular = list()
@@ -219,20 +226,45 @@ class EntityBasedCollisionAvoidance(object):
         ob, _, reward, done, info = self.step(action, update=False, compute_local_map=False)
         return ob, reward, done, info
 
+    def _humans_for_lookahead(self):
+        """ORCA's answer depends on the state only, not on the robot's candidate action
+        (simulator/env.py:395-419 runs the humans before it looks at the action): the first query of a
+        state computes the humans' velocities and leaves them cached in the backend, every later query
+        of the same state — the other 80 of MultiHumanRL.predict's loop, and the real step that follows
+        — reads them (EBC_HUMAN_CACHED)."""
+        if self._human_policy != _abi.HUMAN_ORCA:
+            return self._human_policy
+        if self._humans_cached:
+            return _abi.HUMAN_CACHED
+        self._humans_cached = True
+        self.orca_evaluations += 1
+        return _abi.HUMAN_ORCA
+
     def lookahead_all(self, actions):
         """All candidate actions in one launch: what MultiHumanRL.predict's loop asks for
-        (rl/policy/multi_human_rl.py:38-61).  Returns the backend's arrays for env 0."""
+        (rl/policy/multi_human_rl.py:38-61).  Returns the backend's arrays for env 0, plus `n_rows`
+        (humans + static rows of the scene: the rows the reference would have built)."""
         acts = np.array([[a[0], a[1]] for a in actions], dtype=np.float64)
-        out = self._backend.lookahead(acts, human_policy=self._human_policy)
-        return {k: v[0] for k, v in out.items()}
+        out = self._backend.lookahead(acts, human_policy=self._humans_for_lookahead())
+        self.backend_calls += 1
+        out = {k: v[0] for k, v in out.items()}
+        out["n_rows"] = len(self._humans) + len(self.scene.static_obstacles_as_pedestrians)
+        return out
+
+    def observe_rotated(self):
+        """The rotated joint state of the current state, [rows, T] float32: MultiHumanRL.transform
+        (rl/policy/multi_human_rl.py:128-149) of JointState(robot, last observation)."""
+        n = len(self._humans) + len(self.scene.static_obstacles_as_pedestrians)
+        return self._backend.observe()[1][0, :n].copy()
 
     def step(self, action, update=True, compute_local_map=True, border=None):
         """simulator/env.py:388-466"""
         b = self._backend
         act = self._action_row(action)
         if not update:
-            out = b.lookahead(act, human_policy=self._human_policy, border=self._border(border),
+            out = b.lookahead(act, human_policy=self._humans_for_lookahead(), border=self._border(border),
                               want_rows=False)
+            self.backend_calls += 1
             ob = self._rows_to_ob(out["next_ob"][0])
             nx, ny = self.robot.compute_position(action, self.time_step)
             dg = float(np.linalg.norm(np.array((nx, ny)) - np.array(self.robot.get_goal_position())))
@@ -251,7 +283,9 @@ class EntityBasedCollisionAvoidance(object):
         if hasattr(self.robot.policy, "get_attention_weights"):
             self.attention_weights.append(self.robot.policy.get_attention_weights())
 
-        out = b.step(robot_action=act, human_policy=self._human_policy, border=self._border(border))
+        out = b.step(robot_action=act, human_policy=self._humans_for_lookahead(), border=self._border(border))
+        self.backend_calls += 1
+        self._humans_cached = False  # the state has moved on
         st = b.get_state()
         r = st["robot"][0]
         self.robot.px, self.robot.py, self.robot.vx, self.robot.vy = r[0], r[1], r[2], r[3]
@@ -286,20 +320,38 @@ def make(env_id=ENV_ID, **kwargs):
     return EntityBasedCollisionAvoidance(**kwargs)
 
 
-def configure_env_policy_robot(env_config_path, policy_config_path=None, policy="linear",
-                               phase="test", backend_factory=None):
-    """simulator/utils/test_utils.py:8-36 for the host-side robot policies of this package."""
+def _policy_factory():
+    """rl/policy/policy_factory.py:8-12 extends the simulator's table with the learnt policies.  When the
+    caller's `rl` package is importable its table is used as it is (its SARL then drives this env through
+    `onestep_lookahead`); otherwise `sarl` is this package's own policy (one sweep + one batched forward)."""
+    try:
+        from rl.policy.policy_factory import policy_factory as table
+        return table
+    except ImportError:
+        from .policy import policy_factory
+        from .rl_policy import SARL
+        table = dict(policy_factory)
+        table["sarl"] = SARL
+        return table
+
+
+def configure_env_policy_robot(env_config_path, policy_config_path=None, model_path=None, phase="test",
+                               device="cpu", policy="sarl", env_name=ENV_ID, backend_factory=None):
+    """simulator/utils/test_utils.py:8-36, same positional order (the reference's tests pass the weight
+    file third: tests/test_basic_simulation.py:11-13).  `backend_factory` is this package's test hook."""
+    import torch
     from .agents import Robot
-    from .policy import policy_factory
     env_config = ebc_config.read_config(env_config_path)
-    env = make(backend_factory=backend_factory)
+    env = make(env_name, backend_factory=backend_factory)
     env.configure(env_config)
     robot = Robot(env_config, "robot")
     env.set_robot(robot)
-    pol = policy_factory[policy]()
+    pol = _policy_factory()[policy]()
     if policy_config_path is not None:
         pol.configure(ebc_config.read_config(policy_config_path))
+    if model_path is not None:
+        pol.get_model().load_state_dict(torch.load(model_path, map_location="cpu"))
     robot.set_policy(pol)
     pol.set_phase(phase)
-    pol.set_device("cpu")
+    pol.set_device(device)
     return env, pol, robot

@@ -148,12 +148,13 @@ class SarlValueNet(object):
     def load(cls, path, device="cpu", **kw):
         return cls(torch.load(path, map_location="cpu"), device=device, **kw)
 
-    def forward(self, rows, n_valid=None):
-        """rows [B, R, T] float32; n_valid [B] (rows that exist) or None = all -> values [B]."""
+    def forward(self, rows, n_valid=None, want_weights=False):
+        """rows [B, R, T] float32; n_valid [B] (rows that exist) or None = all -> values [B]
+        (with want_weights: (values, attention weights [B, R]), sarl.py:69-71)."""
         with torch.no_grad():
-            return self._forward(rows, n_valid)
+            return self._forward(rows, n_valid, want_weights)
 
-    def _forward(self, rows, n_valid=None):
+    def _forward(self, rows, n_valid=None, want_weights=False):
         B, R, T = rows.shape
         rows = rows.to(getattr(self, "dtype", torch.float32))
         self_state = rows[:, 0, :self.self_state_dim]
@@ -204,8 +205,15 @@ class SarlValueNet(object):
             attended = (w * feat).sum(dim=1)
         joint = torch.cat([self_state, attended], dim=1)
         if nat is not None and len(nat) > 3:
-            return _mlp(nat[3](joint, True), self.mlp3[2:], False).squeeze(1).to(torch.float32)
-        return _mlp(joint, self.mlp3, False).squeeze(1).to(torch.float32)
+            value = _mlp(nat[3](joint, True), self.mlp3[2:], False).squeeze(1).to(torch.float32)
+        else:
+            value = _mlp(joint, self.mlp3, False).squeeze(1).to(torch.float32)
+        if not want_weights:
+            return value
+        e = torch.exp(scores) * (scores != 0).to(scores.dtype)
+        if n_valid is not None:
+            e = e * (torch.arange(R, device=rows.device)[None, :] < n_valid[:, None])
+        return value, e / e.sum(dim=1, keepdim=True)
 
 
 class DeviceSarlPolicy(object):

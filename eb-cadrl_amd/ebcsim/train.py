@@ -44,19 +44,31 @@ class SarlModule(torch.nn.Module):
         for name, dims in self._layout.items():
             stack(name, dims)
 
+    @staticmethod
+    def _ref_name(k):
+        return k.replace("_weight", ".weight").replace("_bias", ".bias").replace("_", ".", 1)
+
+    def state_dict(self, *args, **kw):
+        """Keys in the reference's layout (`mlp1.0.weight`, ...): what rl/train.py saves and
+        `policy.get_model().load_state_dict(torch.load(path))` (rl/test.py:90) loads."""
+        return {self._ref_name(k): v for k, v in super().state_dict(*args, **kw).items()}
+
+    def load_state_dict(self, sd, strict=True, **kw):
+        own = {self._ref_name(k): k for k, _ in self.named_parameters()}
+        return super().load_state_dict({own.get(k, k): v for k, v in sd.items()}, strict=strict, **kw)
+
     def _stack(self, name):
         n = len(self._layout[name]) - 1
         return [(getattr(self, "%s_%d_weight" % (name, 2 * i)), getattr(self, "%s_%d_bias" % (name, 2 * i)))
                 for i in range(n)]
 
     def reference_state_dict(self):
-        return {k.replace("_weight", ".weight").replace("_bias", ".bias").replace("_", ".", 1): v.detach()
-                for k, v in self.named_parameters()}
+        return {self._ref_name(k): v.detach() for k, v in self.named_parameters()}
 
     def load_reference_state_dict(self, sd):
         with torch.no_grad():
             for k, v in self.named_parameters():
-                v.copy_(sd[k.replace("_weight", ".weight").replace("_bias", ".bias").replace("_", ".", 1)])
+                v.copy_(sd[self._ref_name(k)])
 
     def as_value_net(self):
         net = SarlValueNet.__new__(SarlValueNet)

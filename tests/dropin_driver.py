@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Runs the REFERENCE's own `rl` package (policies, Explorer, test/train scripts, read where it lies under
+the reference root — never copied) against THIS repo's `simulator` package, in a process of its own
+(tests/test_dropin.py starts it; build container only, the reference does not travel).
+
+    dropin_driver.py <reference_root> imports            every module of rl/ that imports `simulator`
+    dropin_driver.py <reference_root> episode <golden>   rl's SARL policy + Explorer-style loop on this
+                                                         repo's env (oracle backend), against the golden
+                                                         the reference's own simulator produced
+
+`gym` and `cv2` are absent from the image: a registry-only `gym` stand-in (what rl/test.py:93 and
+simulator/__init__.py use of it) is installed; it is test scaffolding, not product code."""
+import json
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def install_gym():
+    gym = types.ModuleType("gym")
+    registry = {}
+
+    def register(id, entry_point):
+        registry[id] = entry_point
+
+    def make(id):
+        mod, cls = registry[id].split(":")
+        return getattr(__import__(mod, fromlist=[cls]), cls)()
+
+    class Env(object):
+        pass
+
+    gym.Env, gym.make, gym.register = Env, make, register
+    envs = types.ModuleType("gym.envs")
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = register
+    envs.registration = reg
+    gym.envs = envs
+    sys.modules.update({"gym": gym, "gym.envs": envs, "gym.envs.registration": reg})
+
+
+def main():
+    ref, mode = sys.argv[1], sys.argv[2]
+    install_gym()
+    # this repo's `simulator` first, the reference root (for `rl`) after it
+    sys.path[:0] = [os.path.join(ROOT, "eb-cadrl_amd"), ROOT, HERE, ref]
+    import simulator
+    assert os.path.realpath(simulator.__file__).startswith(os.path.realpath(ROOT)), simulator.__file__
+    if mode == "imports":
+        import importlib
+        names = ["rl.test", "rl.train", "rl.test_parallel", "rl.utils.explorer", "rl.utils.parallel_explorer",
+                 "rl.utils.utils", "rl.policy.policy_factory", "rl.policy.cadrl", "rl.policy.multi_human_rl",
+                 "rl.policy.sarl", "rl.policy.sail", "rl.policy.lstm_rl"]
+        for n in names:
+            m = importlib.import_module(n)
+            assert os.path.realpath(m.__file__).startswith(os.path.realpath(ref)), m.__file__
+        import simulator.policy.orca as o
+        from rl.test import ORCA
+        assert ORCA is o.ORCA
+        print(json.dumps({"imported": names}))
+        return
+
+    import numpy as np
+    import torch
+    import gym
+    from helpers import GOLDEN, load
+    from oracle import oracle
+    from rl.policy.policy_factory import policy_factory
+    from rl.utils.explorer import Explorer
+    from simulator.agents.robot import Robot
+    from simulator.utils.info import ReachGoal
+    import configparser
+
+    z = load(sys.argv[3])
+    meta = json.loads(str(z["meta"]))
+    # rl/test.py:78-107, line for line what that script does before its episode loop
+    policy = policy_factory["sarl"]()
+    policy_config = configparser.RawConfigParser()
+    policy_config.read(os.path.join(ref, meta["policy_config"]))
+    policy.configure(policy_config)
+    policy.get_model().load_state_dict(torch.load(os.path.join(GOLDEN, "weights", meta["weights"])))
+    env_config = configparser.RawConfigParser()
+    env_config.read(os.path.join(ref, meta["config"]))
+    env = gym.make("EntityBasedCollisionAvoidance-v0")
+    env._factory = lambda params, E, N, S: oracle.OracleEnv(params, E, N, S)  # no GPU in this container
+    env.configure(env_config)
+    robot = Robot(env_config, "robot")
+    robot.set_policy(policy)
+    env.set_robot(robot)
+    explorer = Explorer(env, robot, torch.device("cpu"), gamma=policy.gamma)
+    policy.set_phase("test")
+    policy.set_device(torch.device("cpu"))
+    robot.print_info()
+    # rl/test.py:120-135
+    ob, local_map = env.reset("test", meta["seed_case"])
+    done, t, worst = False, 0, 0.0
+    while not done:
+        action = robot.act(ob, local_map=local_map, env=env)
+        if not np.isnan(z["values"][t]).any():
+            worst = max(worst, float(np.abs(np.array(policy.action_values) - z["values"][t]).max()))
+        assert tuple(action) == tuple(z["action"][t]), (t, action, z["action"][t])
+        ob, local_map, reward, done, info = env.step(action)
+        assert abs(reward - z["reward"][t]) <= 1e-9
+        t += 1
+    assert t == len(z["action"]) and isinstance(info, ReachGoal)
+    # one ORCA evaluation per real step, however often the policy asked (81 look-aheads + the step)
+    assert env.orca_evaluations == t, (env.orca_evaluations, t)
+    counts = {"orca_evaluations": env.orca_evaluations, "backend_calls": env.backend_calls}
+    # Explorer.run_k_episodes on one test case: the statistics code path of rl/test.py:137
+    env.scene.case_counter["test"] = meta["seed_case"]
+    m = explorer.run_k_episodes(1, "test", print_failure=True, return_metrics=True)
+    assert m["success_rate"] == 1.0
+    print(json.dumps(dict(counts, steps=t, max_value_err=worst)))
+
+
+if __name__ == "__main__":
+    main()

@@ -710,6 +710,18 @@ def gen_sarl(ref):
     RVO2_MODE["substitute"] = False
 
 
+def gen_sarl_configs(ref):
+    """The env / policy configuration of each SARL run as text (data the reference ships), for the tests
+    that drive the facade with a policy OBJECT (which configures itself from such files)."""
+    table = {}
+    for name, env_path, overrides, pol_path, weights, case in SARL_RUNS:
+        table[name] = {"config_text": cfg_text(os.path.join(ref, env_path), overrides),
+                       "policy_config_text": cfg_text(os.path.join(ref, pol_path))}
+    with open(os.path.join(HERE, "sarl_configs.json"), "w") as f:
+        json.dump(table, f, indent=1)
+    print("wrote sarl_configs.json")
+
+
 # ------------------------------------------------------------- (x) angular local map
 def gen_local_map(ref):
     pol = os.path.join(ref, "configs/test_configs/test_policy_configs/policy.config")
@@ -743,7 +755,8 @@ def gen_local_map(ref):
 
 GENERATORS = {"collisions": gen_collisions, "reward": gen_reward, "grid": gen_grid,
               "rotate": gen_rotate, "action_space": gen_action_space, "scenes": gen_scenes,
-              "trajectories": gen_trajectories, "il": gen_il, "known": gen_known_answers, "sarl": gen_sarl, "local_map": gen_local_map}
+              "trajectories": gen_trajectories, "il": gen_il, "known": gen_known_answers, "sarl": gen_sarl, "sarl_configs": gen_sarl_configs,
+              "local_map": gen_local_map}
 
 
 def main():
