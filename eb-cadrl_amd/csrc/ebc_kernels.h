@@ -76,7 +76,9 @@ struct DevState {
 };
 
 #define EBC_SLOT_EMPTY 0xFFFFFFFFFFFFFFFFull  // two all-ones NaNs: no arithmetic result
+#ifndef EBC_SPIN_LIMIT
 #define EBC_SPIN_LIMIT (1u << 22)               // polls before a consumer gives up (~1 s)
+#endif
 
 struct StepIO {
   const double *robot_action;
@@ -948,6 +950,9 @@ __device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s,
   float ox, oy;
   bool human_ok;
   orca_wave<GS>(p, s, hot, h_ok, e, i, scratch, ox, oy, human_ok);
+#ifdef EBC_WAVE_TRACE  // measurement / test build only: one producer "forgets" its hand-off (tests the give-up path)
+  if (h_ok && (int)hh == g_withhold_human) return;
+#endif
   if (h_ok && j == 0) {
     unsigned long long v = human_ok ? ((unsigned long long)__float_as_uint(oy) << 32) | __float_as_uint(ox) : 0ull;
     if (v == EBC_SLOT_EMPTY) v = 0x7FC000007FC00000ull;  // not an arithmetic result; keeps the protocol total
@@ -1249,6 +1254,14 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
   }
   b -= g.rows_blocks;
   if (EBC_ROLE_MASK & 8) state_role(p_in, s_in, io_in, L, (int)b, g.rows_blocks != 0, lane);
+}
+
+// Observation rows that exist per env (humans + static obstacles as pedestrians, env.py:381-382, :457-458):
+// what the value network's per-pair kernels mask with.  Read from the device state, so it follows restarts
+// from a ragged scene pool.
+__global__ __launch_bounds__(256) void row_counts_kernel(DevState s, long long *out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < s.E) out[e] = (long long)s.n_humans[e] + (s.S ? s.n_static[e] : 0);
 }
 
 // ------------------------------------------------------------------------- observe

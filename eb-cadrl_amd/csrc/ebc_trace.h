@@ -15,6 +15,7 @@ namespace ebc {
 #ifdef EBC_WAVE_TRACE
 __device__ unsigned long long *g_wave_trace;
 __device__ unsigned g_wave_trace_blocks;
+__device__ int g_withhold_human = -1;  // ebc_debug_withhold: the ORCA group of this flat human index never publishes
 __device__ __forceinline__ unsigned long long *wave_trace_row(int tag) {
   if (!g_wave_trace || blockIdx.x >= g_wave_trace_blocks) return nullptr;
   return g_wave_trace + ((size_t)tag * g_wave_trace_blocks + blockIdx.x) * EBC_TRACE_ROW;

@@ -44,6 +44,7 @@ struct Handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   bool has_reset = false;
+  bool faulted = false;  // a mailbox wait timed out and was reported: only ebc_reset re-arms the handle
   int orca_gs = 16;  // lanes per human of the ORCA waves
   unsigned epoch = 0;  // fused ORCA steps launched so far (StepGrid::epoch)
   std::vector<void *> pool_allocs;   // pool arrays (re-allocated by ebc_set_scene_pool)
@@ -79,6 +80,26 @@ int ensure_stage(Handle *h, size_t bytes) {
   return EBC_OK;
 }
 
+// Mailboxes as every launch expects to find them (empty), and the fault word cleared.
+int arm_mailboxes(Handle *h) {
+  const size_t EN = (size_t)h->s.E * h->s.N, E = (size_t)h->s.E;
+  HIP_TRY(hipMemsetAsync(h->s.vel_state, 0xFF, EN * 8, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.vel_rows, 0xFF, EN * 8, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.env_done, 0, E * 4, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.rows_loaded, 0, E * 4, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.fault, 0, 4, h->stream));
+  return EBC_OK;
+}
+
+// Called with the stream idle and the fault word's value in hand: a set word is reported ONCE
+// (EBC_ERR_DEVICE), cleared, and the handle refuses further steps until ebc_reset re-arms it.
+int report_fault(Handle *h, unsigned fault) {
+  if (!fault) return EBC_OK;
+  h->faulted = true;
+  (void)hipMemset(h->s.fault, 0, 4);
+  return fail(EBC_ERR_DEVICE, "ORCA step: a mailbox wait timed out; the state is undefined until ebc_reset");
+}
+
 // A bump allocator over the staging buffer for one host-location call.
 struct Stager {
   Handle *h;
@@ -106,8 +127,10 @@ struct Stager {
   int finish() {
     for (auto &o : outs)
       HIP_TRY(hipMemcpyAsync(o.host, o.dev, o.bytes, hipMemcpyDeviceToHost, h->stream));
+    unsigned fault = 0;  // rides with the copy-back: a host-location call never returns data of a broken step
+    HIP_TRY(hipMemcpyAsync(&fault, h->s.fault, sizeof(fault), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return EBC_OK;
+    return report_fault(h, fault);
   }
 };
 
@@ -492,8 +515,7 @@ int ebc_synchronize(void *handle) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   unsigned fault = 0;  // a role of the fused ORCA step gave up waiting for another (never expected)
   HIP_TRY(hipMemcpy(&fault, h->s.fault, sizeof(fault), hipMemcpyDeviceToHost));
-  if (fault) return fail(EBC_ERR_DEVICE, "ORCA step: a mailbox wait timed out; the state is undefined");
-  return EBC_OK;
+  return report_fault(h, fault);
 }
 
 int ebc_dims(void *handle, int32_t out[5]) {
@@ -557,6 +579,12 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *sc) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
+  // between launches every mailbox is empty; after a reported fault they may not be: re-arm
+  if (h->faulted) {
+    if ((rc = arm_mailboxes(h)) != EBC_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->faulted = false;
+  }
   h->has_reset = true;
   return EBC_OK;
 }
@@ -610,6 +638,7 @@ int ebc_robot_orca(void *handle, double safety_space, int location, double *acti
   int rc = check_handle(handle, &h);
   if (rc) return rc;
   if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_robot_orca before ebc_reset");
+  if (h->faulted) return fail(EBC_ERR_STATE, "ebc_robot_orca: the handle reported a mailbox fault; ebc_reset re-arms it");
   if (!action) return fail(EBC_ERR_INVALID, "null action");
   if (!(safety_space >= 0.0)) return fail(EBC_ERR_INVALID, "safety_space");
   if (h->p.robot_kinematics != EBC_HOLONOMIC) return fail(EBC_ERR_UNSUPPORTED, "ORCA returns ActionXY: holonomic robots only");
@@ -655,6 +684,7 @@ int ebc_step(void *handle, const EbcStepArgs *a) {
   if (rc) return rc;
   if (!a || a->struct_size != sizeof(EbcStepArgs)) return fail(EBC_ERR_INVALID, "EbcStepArgs.struct_size");
   if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_step before ebc_reset");
+  if (h->faulted) return fail(EBC_ERR_STATE, "ebc_step: the handle reported a mailbox fault; ebc_reset re-arms it");
   if (a->human_policy < EBC_HUMAN_EXTERNAL || a->human_policy > EBC_HUMAN_CACHED)
     return fail(EBC_ERR_INVALID, "human_policy");
   if (a->robot_policy == EBC_ROBOT_LINEAR && h->p.robot_kinematics != EBC_HOLONOMIC)
@@ -715,6 +745,7 @@ int ebc_observe(void *handle, int location, double *ob, float *obs_rotated) {
   int rc = check_handle(handle, &h);
   if (rc) return rc;
   if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_observe before ebc_reset");
+  if (h->faulted) return fail(EBC_ERR_STATE, "ebc_observe: the handle reported a mailbox fault; ebc_reset re-arms it");
   const DevState &s = h->s;
   const size_t rows = (size_t)s.E * (s.N + s.S), T = h->T;
   double *d_ob = ob;
@@ -742,6 +773,7 @@ int ebc_lookahead(void *handle, const EbcLookaheadArgs *a) {
   if (!a || a->struct_size != sizeof(EbcLookaheadArgs))
     return fail(EBC_ERR_INVALID, "EbcLookaheadArgs.struct_size");
   if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_lookahead before ebc_reset");
+  if (h->faulted) return fail(EBC_ERR_STATE, "ebc_lookahead: the handle reported a mailbox fault; ebc_reset re-arms it");
   if (!a->actions || a->n_actions <= 0) return fail(EBC_ERR_INVALID, "actions");
   if (a->n_actions > EBC_LA_MAX_ACTIONS) return fail(EBC_ERR_UNSUPPORTED, "more than 128 actions");
   if (a->human_policy != EBC_HUMAN_ORCA && a->human_policy != EBC_HUMAN_LINEAR &&
@@ -774,6 +806,24 @@ int ebc_lookahead(void *handle, const EbcLookaheadArgs *a) {
                                            : launch_lookahead<EBC_HUMAN_EXTERNAL>(h, io);
   if (rc != EBC_OK) return rc;
   if (a->location != EBC_DEVICE) return st.finish();
+  return EBC_OK;
+}
+
+int ebc_row_counts(void *handle, int location, long long *n_rows) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_row_counts before ebc_reset");
+  if (!n_rows) return fail(EBC_ERR_INVALID, "null n_rows");
+  long long *d = n_rows;
+  Stager st{h};
+  if (location != EBC_DEVICE) {
+    if ((rc = ensure_stage(h, pad256((size_t)h->s.E * 8) + 1024)) != EBC_OK) return rc;
+    d = st.out(n_rows, (size_t)h->s.E);
+  }
+  hipLaunchKernelGGL(ebc::row_counts_kernel, dim3((unsigned)((h->s.E + 255) / 256)), dim3(256), 0, h->stream, h->s, d);
+  HIP_TRY(hipGetLastError());
+  if (location != EBC_DEVICE) return st.finish();
   return EBC_OK;
 }
 
@@ -901,7 +951,8 @@ int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int rel
   // (attention block 791 -> 692 us per 0.5 M rows; 5.60 -> 5.17 ms per 1024-env decision batch)
   constexpr int NW = (2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4;
   const size_t lds = 2 * (size_t)(TI + TO) * 2 * 2 * 64 * 16 + (size_t)m->L1.out_tiles * 32 * 4;
-  static size_t raised = 0;  // more than the 64 KB a launch gets by default
+  static size_t raised_dev[64] = {0};  // more than the 64 KB a launch gets by default; a function attribute is per device
+  size_t &raised = raised_dev[m->device & 63];
   if (lds > 65536 && lds > raised) {
     HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1025,6 +1076,12 @@ extern "C" int ebc_debug_wave_trace(void *device_buffer, unsigned blocks) {
   unsigned long long *b = (unsigned long long *)device_buffer;
   if (hipMemcpyToSymbol(HIP_SYMBOL(ebc::g_wave_trace), &b, sizeof(b)) != hipSuccess) return EBC_ERR_DEVICE;
   if (hipMemcpyToSymbol(HIP_SYMBOL(ebc::g_wave_trace_blocks), &blocks, sizeof(blocks)) != hipSuccess) return EBC_ERR_DEVICE;
+  return EBC_OK;
+}
+// tests only: from the next fused ORCA step on, the ORCA group of flat human index `human` (e * N + i) does
+// not publish its velocity, so its consumers run into EBC_SPIN_LIMIT (lowered in this build); -1 = off
+extern "C" int ebc_debug_withhold(int human) {
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ebc::g_withhold_human), &human, sizeof(human)) != hipSuccess) return EBC_ERR_DEVICE;
   return EBC_OK;
 }
 #endif

@@ -83,6 +83,13 @@ class BatchedEnv:
             self.n_static_host = np.zeros(self.E, dtype=np.int64)
         if self.S:
             self.n_static_host[np.arange(scene.n) if ids is None else ids] = scene.n_static
+        self._note_rows(scene)
+
+    def _note_rows(self, scene):
+        """`ragged`: some scene this handle may run has fewer observation rows than R (known on the host
+        from what was uploaded; which env runs which scene is the device's business: row_counts_device)."""
+        rows = np.asarray(scene.n_humans, dtype=np.int64) + (np.asarray(scene.n_static, dtype=np.int64) if self.S else 0)
+        self.ragged = bool(getattr(self, "ragged", False) or (rows < self.R).any())
 
     def set_scene_pool(self, scene, stride=None):
         """Install P = scene.n host-generated scenes as the auto-reset pool; env e walks scenes
@@ -90,6 +97,7 @@ class BatchedEnv:
         keep = []
         sc = self._scene_struct(scene, keep)
         _capi.check(self._L.ebc_set_scene_pool(self._h, C.addressof(sc), int(self.E if stride is None else stride)))
+        self._note_rows(scene)
 
     # ------------------------------------------------------------------ host calls
     def set_human_actions(self, act):
@@ -158,6 +166,18 @@ class BatchedEnv:
     def observe_device(self, obs_rotated):
         """Rotated observation of the current state into a torch CUDA tensor [E, R, T]."""
         _capi.check(self._L.ebc_observe(self._h, _abi.DEVICE, None, obs_rotated.data_ptr()))
+
+    def row_counts(self):
+        """Observation rows that exist per env, int64 [E] (ebc_row_counts), from the device state."""
+        n = np.zeros(self.E, dtype=np.int64)
+        _capi.check(self._L.ebc_row_counts(self._h, _abi.HOST, n.ctypes.data))
+        return n
+
+    def row_counts_device(self, n_rows):
+        """The same into a torch CUDA int64 [E] tensor (enqueued on the handle's stream)."""
+        if n_rows.dtype.itemsize != 8 or n_rows.numel() != self.E or not n_rows.is_contiguous():
+            raise ValueError("n_rows must be a contiguous int64 [E] tensor")
+        _capi.check(self._L.ebc_row_counts(self._h, _abi.DEVICE, n_rows.data_ptr()))
 
     def robot_orca(self, safety_space=0.0):
         """ORCA.predict with the robot as the agent, every env (ebc_robot_orca) -> actions [E, 2]:

@@ -108,16 +108,15 @@ class SarlValueNet(object):
             if ok and self.attention[2][0].shape[0] == 1 and all(
                     st[0][0].shape[1] <= 224 and st[1][0].shape[0] <= 224 for st in stacks):
                 idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-                try:
-                    blocks = [_NativeMlp2(self.mlp1, idx), _NativeMlp2(self.mlp2, idx),
-                              _NativeMlp2(att, idx, final=self.attention[2])]
-                    # mlp3's first two layers (the joint vector's widest ones) as a fourth block; its tail
-                    # (the reference's 200 -> 200 -> 1) stays with torch
-                    if (len(self.mlp3) >= 3 and self.mlp3[0][0].shape[1] <= 224 and self.mlp3[1][0].shape[0] <= 224):
-                        blocks.append(_NativeMlp2(self.mlp3[:2], idx))
-                    self._native = tuple(blocks)
-                except Exception:  # an unsupported shape: stay on the torch path
-                    self._native = ()
+                # the shapes were checked above: a failure from here on is a HIP error and is raised, never
+                # turned into a silent torch path
+                blocks = [_NativeMlp2(self.mlp1, idx), _NativeMlp2(self.mlp2, idx),
+                          _NativeMlp2(att, idx, final=self.attention[2])]
+                # mlp3's first two layers (the joint vector's widest ones) as a fourth block; its tail
+                # (the reference's 200 -> 200 -> 1) stays with torch
+                if (len(self.mlp3) >= 3 and self.mlp3[0][0].shape[1] <= 224 and self.mlp3[1][0].shape[0] <= 224):
+                    blocks.append(_NativeMlp2(self.mlp3[:2], idx))
+                self._native = tuple(blocks)
             else:
                 self._native = ()
         return getattr(self, "_native", ()) or None
@@ -160,6 +159,7 @@ class SarlValueNet(object):
         self_state = rows[:, 0, :self.self_state_dim]
         nat = None if torch.is_grad_enabled() or not rows.is_cuda else self._native_blocks()
         if nat is not None:
+            self.native_forwards = getattr(self, "native_forwards", 0) + 1  # tests assert the HIP path ran
             h1 = nat[0](rows.reshape(B * R, T), True)
             feat = nat[1](h1, False).view(B, R, -1)
         else:
@@ -242,9 +242,10 @@ class DeviceSarlPolicy(object):
     def decide(self, env, human_policy=_abi.HUMAN_ORCA):
         """env: BatchedEnv on this net's device.  Returns (actions [E, 2] float64 CUDA tensor,
         values [E, A]); the human velocities stay cached for a following EBC_HUMAN_CACHED step.
-        The sweep's buffers and the envs' row counts are taken when an env batch is first seen (a
-        different batch re-allocates them): a scene pool whose scenes differ in their number of humans
-        or static rows needs a fresh policy object (or `_bufs = None`) after the counts change."""
+        The sweep's buffers are taken when an env batch is first seen (a different batch re-allocates
+        them).  The rows that exist per env are read from the DEVICE state at every decision when the
+        handle may run scenes of different sizes (`env.ragged`: a ragged reset batch or scene pool), so a
+        restart inside the step cannot leave them stale; `self.n_valid` is what the last decision used."""
         dev = self.net.device
         A = len(self.actions_np)
         key = (id(env), env.E, env.R, env.T)
@@ -252,14 +253,14 @@ class DeviceSarlPolicy(object):
             self._env_key = key
             self._acts = torch.tensor(self.actions_np, dtype=torch.float64, device=dev)
             self._bufs = env.alloc_lookahead_outputs(A, ("reward", "rows_rotated"))
-            st = env.get_state()
-            nv = st["n_humans"].astype(np.int64) + (env.n_static_host if hasattr(env, "n_static_host") else 0)
-            self._n_valid = torch.tensor(nv, device=dev)
-            self._v_pref = float(st["robot"][0, 7])
-            self._radius = torch.tensor(st["robot"][:, 4], device=dev)
+            self._n_valid = torch.full((env.E,), env.R, dtype=torch.int64, device=dev)
+            self._v_pref = float(env.get_state()["robot"][0, 7])
+        self.n_valid = None
+        if getattr(env, "ragged", False):
+            env.row_counts_device(self._n_valid)
+            self.n_valid = self._n_valid
         env.lookahead_device(self._acts, self._bufs, human_policy=human_policy)
-        n_valid = self._n_valid if int(self._n_valid.min()) < env.R else None
-        values = self.values_from(self._bufs["rows_rotated"], self._bufs["reward"], n_valid,
+        values = self.values_from(self._bufs["rows_rotated"], self._bufs["reward"], self.n_valid,
                                   env.params.time_step, self._v_pref)
         best = torch.argmax(values, dim=1)
         return self._acts[best], values

@@ -86,33 +86,57 @@ class SarlModule(torch.nn.Module):
 
 
 class DeviceReplay(object):
-    """Ring buffer of (rotated joint state [R, T], value) pairs in device memory."""
+    """Ring buffer of (rotated joint state [R, T], value, rows that exist) triples in device memory.
+    `n_valid` is what the reference's variable-length state tensors carry implicitly (an env with fewer
+    humans + static rows than R has padding rows the network must not see, multi_human_rl.py:128-149)."""
 
     def __init__(self, capacity, R, T, device):
         self.states = torch.zeros((capacity, R, T), dtype=torch.float32, device=device)
         self.values = torch.zeros(capacity, dtype=torch.float32, device=device)
-        self.capacity, self.position, self.size = int(capacity), 0, 0
+        self.n_valid = torch.full((capacity,), R, dtype=torch.int64, device=device)
+        self.capacity, self.position, self.size, self.R = int(capacity), 0, 0, int(R)
+        self.ragged = False  # any pair with fewer than R rows
 
-    def push(self, states, values):
+    def push(self, states, values, n_valid=None):
         n = states.shape[0]
+        if n == 0:
+            return
+        total = n
+        if n > self.capacity:  # only the newest `capacity` items survive a ring: no duplicate slots in one write
+            states, values = states[-self.capacity:], values[-self.capacity:]
+            n_valid = None if n_valid is None else n_valid[-self.capacity:]
+            self.position = (self.position + n - self.capacity) % self.capacity
+            n = self.capacity
         idx = (torch.arange(n, device=states.device) + self.position) % self.capacity
         self.states[idx] = states
         self.values[idx] = values.to(torch.float32)
+        if n_valid is None:
+            self.n_valid[idx] = self.R
+        else:  # callers pass row counts only for handles that may run ragged scenes (no device sync here)
+            self.n_valid[idx] = n_valid.to(torch.int64)
+            self.ragged = True
         self.position = (self.position + n) % self.capacity
-        self.size = min(self.capacity, self.size + n)
+        self.size = min(self.capacity, self.size + total)
 
-    def sample(self, batch_size, generator=None):
+    def rows_of(self, idx):
+        """n_valid for model(states[idx], n_valid) — None while every stored pair has all R rows."""
+        return self.n_valid[idx] if self.ragged else None
+
+    def sample(self, batch_size, generator=None, with_rows=False):
         idx = torch.randint(0, self.size, (batch_size,), device=self.states.device, generator=generator)
+        if with_rows:
+            return self.states[idx], self.values[idx], self.rows_of(idx)
         return self.states[idx], self.values[idx]
 
     def __len__(self):
         return self.size
 
 
-def value_targets(reward, done, next_states, target_net, gamma_bar):
-    """explorer.py:171-184: terminal -> reward; else reward + gamma_bar * V_target(s')."""
+def value_targets(reward, done, next_states, target_net, gamma_bar, n_valid=None):
+    """explorer.py:171-184: terminal -> reward; else reward + gamma_bar * V_target(s').  n_valid: rows of
+    each next state that exist (None = all R)."""
     with torch.no_grad():
-        nxt = target_net.forward(next_states)
+        nxt = target_net.forward(next_states, n_valid)
     return torch.where(done.bool(), reward, reward + gamma_bar * nxt.to(reward.dtype))
 
 
@@ -152,15 +176,18 @@ class EpisodeStore(object):
     def __init__(self, E, T_max, R, T, device):
         self.states = torch.zeros((T_max, E, R, T), dtype=torch.float32, device=device)
         self.values = torch.zeros((T_max, E), dtype=torch.float32, device=device)
+        self.n_valid = torch.full((T_max, E), R, dtype=torch.int64, device=device)
         self.length = torch.zeros(E, dtype=torch.int64, device=device)
         self.T_max, self.E = int(T_max), int(E)
         self._env = torch.arange(E, device=device)
         self._t = torch.arange(T_max, device=device)[:, None]
 
-    def add(self, states, values):
+    def add(self, states, values, n_valid=None):
         t = self.length.clamp(max=self.T_max - 1)  # an episode cannot outlast time_limit / time_step steps
         self.states[t, self._env] = states
         self.values[t, self._env] = values.to(torch.float32)
+        if n_valid is not None:
+            self.n_valid[t, self._env] = n_valid.to(torch.int64)
         self.length = (self.length + 1).clamp(max=self.T_max)
 
     def end(self, done, info, memory):
@@ -171,9 +198,39 @@ class EpisodeStore(object):
         if bool(go.any()):
             mask = (self._t < self.length[None, :]) & go[None, :]
             n = int(mask.sum())
-            memory.push(self.states[mask], self.values[mask])
+            memory.push(self.states[mask], self.values[mask], self.n_valid[mask])
         self.length = torch.where(done, torch.zeros_like(self.length), self.length)
         return n
+
+
+def _multi_rank():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def all_ranks(flag, device=None):
+    """True on every rank iff `flag` holds on EVERY rank (one MIN all-reduce).  Branches that contain
+    collectives (the gradient all-reduce of an optimizer step) must be taken by all ranks or by none."""
+    if not _multi_rank():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def broadcast_parameters_(model, src=0):
+    """Every replica starts from rank `src`'s weights (one flat broadcast), whatever seeds the ranks ran
+    their constructors with; the reference's workers get theirs from the parent process
+    (rl/utils/parallel_explorer.py:59-70)."""
+    if not _multi_rank():
+        return
+    params = list(model.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for p in params])
+    dist.broadcast(flat, src=src)
+    off = 0
+    with torch.no_grad():
+        for p in params:
+            p.copy_(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
 
 
 def allreduce_flat_(params):
@@ -228,7 +285,8 @@ class DataParallelTrainer(object):
             for b in range(batches):
                 idx = perm[b * self.batch_size:(b + 1) * self.batch_size]
                 self.optimizer.zero_grad()
-                loss = self.criterion(self.model(self.memory.states[idx]), self.memory.values[idx])
+                loss = self.criterion(self.model(self.memory.states[idx], self.memory.rows_of(idx)),
+                                      self.memory.values[idx])
                 loss.backward()
                 allreduce_flat_(params)
                 self.optimizer.step()
@@ -240,9 +298,12 @@ class DataParallelTrainer(object):
         losses = 0.0
         params = list(self.model.parameters())
         for _ in range(num_batches):
-            inputs, values = self.memory.sample(self.batch_size, generator)
+            if getattr(self.memory, "ragged", False):
+                inputs, values, rows = self.memory.sample(self.batch_size, generator, with_rows=True)
+            else:
+                (inputs, values), rows = self.memory.sample(self.batch_size, generator), None
             self.optimizer.zero_grad()
-            loss = self.criterion(self.model(inputs), values)
+            loss = self.criterion(self.model(inputs, rows), values)
             loss.backward()
             allreduce_flat_(params)
             self.optimizer.step()
@@ -266,23 +327,28 @@ def collect(env, policy, target_net, memory, steps, gamma, epsilon=0.0, generato
     gamma_bar = gamma ** (env.params.time_step * v_pref)
     A = len(policy.actions_np)
     total = 0.0
+    ragged = bool(getattr(env, "ragged", False))
     for _ in range(steps):
         actions, _ = policy.decide(env, human_policy=human_policy)
+        nv_cur = policy.n_valid.clone() if ragged else None  # rows of `cur` (the state the decision saw)
         if epsilon > 0:
             explore = torch.rand(E, device=dev, generator=generator) < epsilon
             rnd = torch.randint(0, A, (E,), device=dev, generator=generator)
             actions = torch.where(explore[:, None], policy._acts[rnd], actions)
         env.step_device(outs, robot_action=actions.contiguous(), human_policy=_abi.HUMAN_CACHED,
                         flags=_abi.FLAG_AUTO_RESET)
-        targets = value_targets(outs["reward"], outs["done"], outs["obs_rotated"], target_net, gamma_bar)
+        # the returned observation belongs to the scene that was stepped (a terminal env's target is its
+        # reward, its restart scene shows up in `cur` below): its row count is the decision's
+        targets = value_targets(outs["reward"], outs["done"], outs["obs_rotated"], target_net, gamma_bar, nv_cur)
         if store is None:
-            memory.push(cur.clone(), targets)
+            memory.push(cur.clone(), targets, nv_cur)
         else:
-            store.add(cur, targets)
+            store.add(cur, targets, nv_cur)
             store.end(outs["done"], outs["info"], memory)
         total += float(outs["reward"].mean())
         # the next decision's state: the returned observation, or the reset scene after a terminal step
         env.observe_device(cur)
+    env.synchronize()  # surfaces a mailbox fault of any step above (EBC_ERR_DEVICE) instead of training on it
     return total / steps
 
 
@@ -302,8 +368,12 @@ def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HU
     outs = env.alloc_step_outputs(("reward", "done", "info"))
     v_pref = float(env.get_state()["robot"][0, 7])
     gamma_bar = gamma ** (env.params.time_step * v_pref)
+    ragged = bool(getattr(env, "ragged", False))
+    rows = torch.full((steps, E), R, dtype=torch.int64, device=dev) if ragged else None
     for t in range(steps):
         env.observe_device(states[t])        # policy.last_state, transformed (explorer.py:43, :162)
+        if ragged:
+            env.row_counts_device(rows[t])
         env.robot_orca_device(act, safety_space)
         env.step_device(outs, robot_action=act, human_policy=human_policy, flags=_abi.FLAG_AUTO_RESET)
         rewards[t].copy_(outs["reward"])
@@ -311,7 +381,9 @@ def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HU
         infos[t].copy_(outs["info"])
     values, keep = il_value_targets(rewards, dones, gamma_bar, infos)
     keep = keep.reshape(-1)
-    memory.push(states.reshape(steps * E, R, T)[keep], values.reshape(-1)[keep])
+    memory.push(states.reshape(steps * E, R, T)[keep], values.reshape(-1)[keep],
+                rows.reshape(-1)[keep] if ragged else None)
+    env.synchronize()  # a natural sync point: also surfaces a mailbox fault of any step above
     return int(keep.sum()), int(dones.sum())
 
 
@@ -347,15 +419,26 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
         if rank == 0 and output_dir:
             os.makedirs(output_dir, exist_ok=True)
             torch.save({k: v.cpu() for k, v in model.reference_state_dict().items()}, path)
-    if il_file and os.path.exists(il_file):
-        model.load_reference_state_dict(torch.load(il_file, map_location="cpu"))
+    # Rank 0 decides whether the imitation-learning stage is skipped (it is the rank that writes the file),
+    # and its weights are every replica's starting point: the stages below contain collectives, so all
+    # ranks must walk the same schedule.
+    found = bool(il_file and os.path.exists(il_file)) if rank == 0 else False
+    if _multi_rank():
+        t = torch.tensor([1 if found else 0], dtype=torch.int32, device=dev if dev.type == "cuda" and dist.get_backend() == "nccl" else None)
+        dist.broadcast(t, src=0)
+        found = bool(int(t.item()))
+    if found:
+        if rank == 0 or os.path.exists(il_file):
+            model.load_reference_state_dict(torch.load(il_file, map_location="cpu"))
         hist["il_loaded"] = True
         il_steps = 0
         if log:
             log("imitation learning: weights loaded from %s" % il_file)
+    broadcast_parameters_(model, 0)
+    red_dev = dev if (dev.type == "cuda" and _multi_rank() and dist.get_backend() == "nccl") else None
     if il_steps > 0:
         hist["il_stored"], hist["il_episodes"] = collect_il(env, memory, il_steps, gamma, il_safety_space)
-        if len(memory) and il_epochs > 0:
+        if il_epochs > 0 and all_ranks(len(memory) > 0, red_dev):  # every rank's shard has data, or nobody trains
             hist["il_loss"] = trainer.optimize_epoch(il_epochs, generator)
         if il_file:
             save(il_file)
@@ -379,7 +462,9 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
         eps = epsilon_start + (epsilon_end - epsilon_start) / epsilon_decay * it if it < epsilon_decay else epsilon_end
         mean_r = collect(env, policy, target.as_value_net(), memory, steps_per_iteration, gamma, epsilon=eps,
                          generator=generator, store=store)
-        loss = trainer.optimize_batch(train_batches, generator) if len(memory) else float("nan")
+        # ranks fill their shards at different times (an episode reaches the memory when it ends): the
+        # optimizer steps all-reduce gradients, so a round trains on every rank or on none
+        loss = trainer.optimize_batch(train_batches, generator) if all_ranks(len(memory) > 0, red_dev) else float("nan")
         if (it + 1) % target_update_interval == 0:
             target.load_state_dict(model.state_dict())
         hist["rl_loss"].append(loss)
@@ -432,6 +517,7 @@ def evaluate(env, decide, gamma, max_steps=None, human_policy=_abi.HUMAN_ORCA):
         alive = alive & ~ended
         if t % 8 == 7 and not bool(alive.any()):
             break
+    env.synchronize()  # before the metrics: a broken step must not be counted
     final, end_time = final.cpu().numpy(), end_time.cpu().numpy()
     if (final < 0).any():
         raise ValueError("Invalid end signal from environment")  # explorer.py:80: every episode must end

@@ -246,10 +246,19 @@ int ebc_robot_orca(void *handle, double safety_space, int location, double *acti
  * EBC_HUMAN_ORCA it is ONE kernel launch whose arguments change from call to call (the robot state
  * is double-buffered and a launch counter travels with the launch): call it once per step; do not
  * capture it in a HIP graph and replay it.  A broken hand-off inside that launch (never seen)
- * surfaces as EBC_ERR_DEVICE from ebc_synchronize, not as a hang. */
+ * surfaces as EBC_ERR_DEVICE — not as a hang — from ebc_synchronize or from the next host-location
+ * call (whose copy-back carries the fault word); it is reported once, the handle then refuses
+ * steps (EBC_ERR_STATE) until ebc_reset has re-armed it. */
 int ebc_step(void *handle, const EbcStepArgs *args);
 int ebc_lookahead(void *handle, const EbcLookaheadArgs *args);
 int ebc_get_state(void *handle, const EbcStateView *view);
+
+/* Rows of the observation that exist, per env: len(ob) of the list env.step returns (humans, then the
+ * static obstacles as pedestrians: simulator/env.py:381-382, :457-458) — the first dimension of the
+ * state tensor MultiHumanRL.transform builds (rl/policy/multi_human_rl.py:128-149).  n_rows [E] int64
+ * (what ebc_pair_mean / ebc_pair_attend take as n_valid).  Read from the device state, so it follows
+ * auto-reset restarts from a scene pool whose scenes differ in size. */
+int ebc_row_counts(void *handle, int location, long long *n_rows);
 
 /* Geometry of the handle (E, N, S, T, G). */
 int ebc_dims(void *handle, int32_t out[5]);

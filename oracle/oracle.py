@@ -338,6 +338,10 @@ class OracleEnv:
             raise RuntimeError("orc_robot_orca failed: %d" % rc)
         return act
 
+    def row_counts(self):
+        """Observation rows that exist per env (the checker's ebc_row_counts)."""
+        return self.a["n_humans"].astype(np.int64) + (self.a["n_static"].astype(np.int64) if self.S else 0)
+
     def get_state(self):
         keys = ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type", "n_humans",
                 "robot", "global_time", "arrival_time", "done")

@@ -710,6 +710,48 @@ def gen_sarl(ref):
     RVO2_MODE["substitute"] = False
 
 
+def gen_sarl_rl_memory(ref):
+    """The RL-mode replay content of one episode, by the reference's own code: its SARL policy in phase
+    "train" (epsilon 0: greedy, but `last_state = transform(state)` is kept, multi_human_rl.py:84-85), the
+    episode loop of Explorer.run_one_episode (explorer.py:33-45), then Explorer.update_memory(...,
+    imitation_learning=False) with the target model set by update_target_model (explorer.py:171-184;
+    rl/train.py:195, :239-259).  Stored: every (state, value) pair the reference put in its ReplayMemory."""
+    import torch
+    from rl.utils.explorer import Explorer
+    from rl.utils.memory import ReplayMemory
+    from simulator.utils.test_utils import configure_env_policy_robot
+    RVO2_MODE["substitute"] = True
+    name, env_path, overrides, pol_path, weights, case = SARL_RUNS[0]
+    text = cfg_text(os.path.join(ref, env_path), overrides)
+    tmp = write_tmp(text)
+    try:
+        env, pol, robot = configure_env_policy_robot(tmp, os.path.join(ref, pol_path), os.path.join(ref, weights),
+                                                     phase="train")
+    finally:
+        os.unlink(tmp)
+    pol.set_epsilon(0.0)
+    memory = ReplayMemory(100000)
+    ex = Explorer(env, robot, "cpu", memory, pol.gamma, target_policy=pol)
+    ex.update_target_model(pol.get_model())
+    ob, _ = env.reset("test", test_case=case, compute_local_map=False)
+    done, states, actions, rewards, infos = False, [], [], [], []
+    while not done:
+        action = robot.act(ob, env=env)
+        ob, _, reward, done, info = env.step(action, compute_local_map=False)
+        states.append(robot.policy.last_state)
+        actions.append(action)
+        rewards.append(reward)
+        infos.append(info_code(info))
+    ex.update_memory(states, actions, rewards, imitation_learning=False)
+    ref_run = np.load(os.path.join(HERE, name + ".npz"))
+    assert np.array_equal(np.array([[a[0], a[1]] for a in actions]), ref_run["action"]), "greedy episode differs"
+    save("sarl_a5_rl_memory", rl_state=np.stack([m[0].numpy() for m in memory.memory]),
+         rl_value=np.array([float(m[1][0]) for m in memory.memory]), reward=np.array(rewards, float),
+         info=np.array(infos), gamma=np.array(pol.gamma), robot_v_pref=np.array(robot.v_pref),
+         time_step=np.array(env.time_step), episode_of=np.array(name))
+    RVO2_MODE["substitute"] = False
+
+
 def gen_sarl_configs(ref):
     """The env / policy configuration of each SARL run as text (data the reference ships), for the tests
     that drive the facade with a policy OBJECT (which configures itself from such files)."""
@@ -755,7 +797,7 @@ def gen_local_map(ref):
 
 GENERATORS = {"collisions": gen_collisions, "reward": gen_reward, "grid": gen_grid,
               "rotate": gen_rotate, "action_space": gen_action_space, "scenes": gen_scenes,
-              "trajectories": gen_trajectories, "il": gen_il, "known": gen_known_answers, "sarl": gen_sarl, "sarl_configs": gen_sarl_configs,
+              "trajectories": gen_trajectories, "il": gen_il, "known": gen_known_answers, "sarl": gen_sarl, "sarl_rl": gen_sarl_rl_memory, "sarl_configs": gen_sarl_configs,
               "local_map": gen_local_map}
 
 

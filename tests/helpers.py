@@ -112,3 +112,80 @@ def check_trajectory(env, z, atol=1e-9, rot_atol=1e-5, lookahead=True):
         if E > 1:  # every replica of the scene must agree with env 0
             for key in ("reward", "info", "obs_rotated"):
                 assert (out[key] == out[key][0:1]).all(), msg
+
+
+class CpuDeviceEnv(object):
+    """The *_device call surface of ebcsim.batched.BatchedEnv on CPU torch tensors, computed by the
+    oracle: lets the trainer's schedule (ebcsim/train.py: collect, collect_il, run_training — host
+    logic over that surface) run under gloo without a GPU.  Test scaffolding only."""
+
+    def __init__(self, params, E, N, S):
+        from oracle import oracle
+        self._o = oracle.OracleEnv(params, E, N, S)
+        self.params, self.E, self.N, self.S, self.R, self.T = params, E, N, S, N + S, self._o.T
+        self.device = 0
+        self.ragged = False
+        self.steps = 0
+
+    def _note(self, scene):
+        rows = np.asarray(scene.n_humans, np.int64) + (np.asarray(scene.n_static, np.int64) if self.S else 0)
+        self.ragged = bool(self.ragged or (rows < self.R).any())
+
+    def reset(self, scene, env_ids=None):
+        self._o.reset(scene, env_ids)
+        self._note(scene)
+
+    def set_scene_pool(self, scene, stride=None):
+        self._o.set_scene_pool(scene, stride)
+        self._note(scene)
+
+    def get_state(self):
+        return self._o.get_state()
+
+    def use_torch_stream(self):
+        pass
+
+    def synchronize(self):
+        pass
+
+    def alloc_step_outputs(self, keys=("reward", "done", "info", "obs_rotated")):
+        import torch
+        E, N, R, T = self.E, self.N, self.R, self.T
+        shapes = dict(reward=((E,), torch.float64), done=((E,), torch.uint8), info=((E,), torch.uint8),
+                      dmin=((E, 3), torch.float64), dist_to_goal=((E,), torch.float64),
+                      obs_rotated=((E, R, T), torch.float32))
+        return {k: torch.zeros(shapes[k][0], dtype=shapes[k][1]) for k in keys}
+
+    def alloc_lookahead_outputs(self, n_actions, keys=("reward", "done", "info", "rows_rotated")):
+        import torch
+        E, R, T, A = self.E, self.R, self.T, int(n_actions)
+        shapes = dict(reward=((E, A), torch.float64), done=((E, A), torch.uint8), info=((E, A), torch.uint8),
+                      rows_rotated=((E, A, R, T), torch.float32))
+        return {k: torch.zeros(shapes[k][0], dtype=shapes[k][1]) for k in keys}
+
+    def step_device(self, outputs, robot_action=None, human_policy=_abi.HUMAN_ORCA,
+                    robot_policy=_abi.ROBOT_EXTERNAL, flags=0):
+        import torch
+        out = self._o.step(robot_action=None if robot_action is None else robot_action.numpy(),
+                           human_policy=human_policy, robot_policy=robot_policy, flags=flags)
+        for k, t in outputs.items():
+            t.copy_(torch.from_numpy(out[k]))
+        self.steps += 1
+
+    def lookahead_device(self, actions, outputs, human_policy=_abi.HUMAN_ORCA, flags=0):
+        import torch
+        out = self._o.lookahead(actions.numpy(), human_policy=human_policy, flags=flags)
+        for k, t in outputs.items():
+            t.copy_(torch.from_numpy(out[k]))
+
+    def observe_device(self, obs_rotated):
+        import torch
+        obs_rotated.copy_(torch.from_numpy(self._o.observe()[1]))
+
+    def row_counts_device(self, n_rows):
+        import torch
+        n_rows.copy_(torch.from_numpy(self._o.row_counts()))
+
+    def robot_orca_device(self, actions, safety_space=0.0):
+        import torch
+        actions.copy_(torch.from_numpy(self._o.robot_orca(safety_space)))

@@ -1,0 +1,52 @@
+"""bench.py --gpus N without an external launcher: the parent starts N rank processes with the
+torch.distributed.run environment and relays rank 0's line (BASELINE configs 4/5 scale the way the reference
+does with its Pool(8), rl/train.py:19).  The rank program here is a stand-in that does what a bench rank does
+with torch.distributed on gloo — rendezvous from the env, a max-reduce of its time, a sum of its units —
+so the spawn path is covered without a GPU."""
+import json
+import os
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+RANK_PROGRAM = textwrap.dedent("""
+    import json, os, sys
+    sys.path[:0] = [%r, %r]
+    import torch.distributed as dist
+    from ebcsim import shard
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["LOCAL_RANK"]) == rank
+    dist.init_process_group("gloo")
+    elapsed, units = shard.job_rate(1.0 + rank, 40960.0)
+    if len(sys.argv) > 1 and int(sys.argv[1]) == rank:
+        sys.exit(3)
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "elapsed": elapsed, "units": units}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""") % (ROOT, os.path.join(ROOT, "eb-cadrl_amd"))
+
+
+def test_launch_ranks_relays_rank0_and_reduces():
+    import bench
+    rc, out = bench.launch_ranks(2, [sys.executable, "-c", RANK_PROGRAM], timeout=300)
+    assert rc == 0, out
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line == {"n_gpus": 2, "elapsed": 2.0, "units": 81920.0}  # max over ranks, sum of units
+
+
+def test_launch_ranks_reports_a_failed_rank():
+    import bench
+    rc, out = bench.launch_ranks(2, [sys.executable, "-c", RANK_PROGRAM, "1"], timeout=300)
+    assert rc != 0
+
+
+def test_parent_does_not_touch_the_gpu_before_spawning():
+    """The self-launch branch sits before any torch import in main(): the parent must stay free of HIP state
+    (a process that initialised the GPU must not start replacing itself, and need not hold a context)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("launch_ranks(") < main.index("import torch")
+    assert "os.exec" not in src

@@ -283,6 +283,78 @@ def test_full_size_parity_vs_oracle():
         np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
 
 
+BASELINE_SIZES = [
+    # (bench workload, envs on one GPU, humans by, steps): BASELINE.json configs 2, 3 and the per-GPU slice of 4
+    ("cfg2", 4096, "external", 12),   # 4096 x 5, human velocities supplied by the host (ORCA on host = the oracle)
+    ("cfg3", 16384, "orca", 12),      # 16384 x 10 + 4 walls, ORCA as a HIP kernel
+    ("cfg4", 16384, "orca", 12),      # 131072 x 5 over 8 GPUs: one rank's 16384-env slice
+]
+
+
+@pytest.mark.parametrize("workload,E,humans,steps", BASELINE_SIZES)
+def test_baseline_sizes_vs_oracle(workload, E, humans, steps):
+    """The other BASELINE configurations at their full one-GPU size, every env every step against the
+    oracle (its env loop on all host threads), scenes from bench.py's own builder (rank 3 of 8 for the
+    config-4 slice: the seeds that rank would own)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import oracle
+    params, b = bench.build_batch(workload, E, 3 if workload == "cfg4" else 0)
+    assert b.n == E and (b.N, b.S) == {"cfg2": (5, 0), "cfg3": (10, 8), "cfg4": (5, 0)}[workload]
+    params.time_limit = 2  # restarts inside the window (step 8)
+    g = _env(params, E, b.N, b.S)
+    o = oracle.OracleEnv(params, E, b.N, b.S)
+    g.reset(b)
+    o.reset(b)
+    g.use_torch_stream()
+    outs = g.alloc_step_outputs(("reward", "done", "info", "obs_rotated", "human_action"))
+    fl = _abi.FLAG_AUTO_RESET
+    oracle.set_threads(bench.host_cores())
+    try:
+        restarts = 0
+        for t in range(steps):
+            ref = o.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+            if humans == "external":
+                g.set_human_actions(ref["human_action"])
+                g.step_device(outs, human_policy=_abi.HUMAN_EXTERNAL, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+            else:
+                g.step_device(outs, human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+            g.synchronize()
+            np.testing.assert_array_equal(outs["done"].cpu().numpy(), ref["done"], err_msg="step %d" % t)
+            np.testing.assert_array_equal(outs["info"].cpu().numpy(), ref["info"], err_msg="step %d" % t)
+            np.testing.assert_allclose(outs["reward"].cpu().numpy(), ref["reward"], atol=1e-9, rtol=0)
+            np.testing.assert_allclose(outs["human_action"].cpu().numpy(), ref["human_action"], atol=1e-9, rtol=0)
+            np.testing.assert_allclose(outs["obs_rotated"].cpu().numpy(), ref["obs_rotated"], atol=1e-5, rtol=1e-5)
+            restarts += int(ref["done"].sum())
+        assert restarts >= E
+    finally:
+        oracle.set_threads(1)
+    sg, so = g.get_state(), o.get_state()
+    for k in sg:
+        np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
+
+
+def test_mailbox_fault_is_reported_once_and_reset_rearms():
+    """The give-up path of the one-launch step (ebc_kernels.h mailbox_wait / EBC_SPIN_LIMIT), never taken in a
+    healthy run, exercised ONCE with the test build: a withheld hand-off ends in EBC_ERR_DEVICE instead of a
+    hang, is reported once, the handle refuses steps until ebc_reset, and then matches the oracle again."""
+    import subprocess
+    import sys
+    lib = os.path.join(os.path.dirname(GOLDEN), "..", "eb-cadrl_amd", "lib", "libebcsim_fault.so")
+    if not os.path.exists(lib):
+        pytest.fail("libebcsim_fault.so is not built (make -C eb-cadrl_amd/csrc fault; __graft_entry__.build() does)")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(GOLDEN), "fault_driver.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["healthy_steps"] == 3
+    assert out["first"] == _abi.ERR_DEVICE            # surfaced by the call that ran the broken step
+    assert out["sync_after"] == _abi.OK               # reported once, flag cleared
+    assert out["step_while_faulted"] == _abi.ERR_STATE
+    assert out["after_reset_max_err"] <= 1e-5 and out["sync_end"] == _abi.OK
+
+
 def test_device_resident_step_matches_host_step():
     import torch
     z = load("traj_a5_linear_orcasub")

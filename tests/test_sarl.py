@@ -1,8 +1,8 @@
 """Robot decisions = look-ahead sweep + SARL value network.  Golden: the
 reference's own SARL policy (its shipped weights) driving full episodes, 81 action values per
 decision (tests/golden/sarl_*.npz, humans on the oracle-substituted rvo2).  Values are float32
-network outputs on O(1) numbers: 2e-4 absolute; the chosen action must be the reference's
-unless the two best values are closer than that."""
+network outputs on O(1) numbers: 5e-5 absolute (observed <= 1.5e-5 with the split-bf16 matrix-core
+blocks); EVERY decision must pick the reference's action (counted per episode)."""
 import json
 import os
 
@@ -15,17 +15,16 @@ from ebcsim.sarl import DeviceSarlPolicy, SarlValueNet
 from helpers import GOLDEN, batch_from_init, load, params_of
 
 RUNS = ["sarl_a5_baseline", "sarl_n10_ebcadrl"]
-TOL = 2e-4
+TOL = 5e-5
 
 
 def _check_values(values, z, t):
+    """-> 1 when the decision picks the reference's action"""
     ref = z["values"][t]
     np.testing.assert_allclose(values, ref, atol=TOL, rtol=0, err_msg="decision %d" % t)
     best = int(np.argmax(values))
     chosen = int(np.where((z["action_space"] == z["action"][t]).all(1))[0][0])
-    if best != chosen:
-        top = np.sort(ref)[-2:]
-        assert top[1] - top[0] < TOL, (t, best, chosen)
+    return int(best == chosen)
 
 
 @pytest.mark.parametrize("name", RUNS)
@@ -42,14 +41,17 @@ def test_sarl_values_cpu(name):
     pol = DeviceSarlPolicy(net, z["action_space"], meta["gamma"])
     v_pref = float(b.robot[0, 7])
     steps = min(len(z["action"]), 40)
+    agree = decided = 0
     for t in range(steps):
         la = env.lookahead(z["action_space"], human_policy=_abi.HUMAN_ORCA)
         if not np.isnan(z["values"][t]).any():
             vals = pol.values_from(torch.from_numpy(la["rows_rotated"]), torch.from_numpy(la["reward"]),
                                    None, params.time_step, v_pref)
-            _check_values(vals[0].numpy(), z, t)
+            agree += _check_values(vals[0].numpy(), z, t)
+            decided += 1
         out = env.step(robot_action=z["action"][t][None], human_policy=_abi.HUMAN_CACHED)
         assert int(out["info"][0]) == int(z["info"][t])
+    assert agree == decided, (agree, decided)
 
 
 @pytest.mark.gpu
@@ -68,19 +70,74 @@ def test_sarl_decisions_gpu(name):
     net = SarlValueNet.load(os.path.join(GOLDEN, "weights", meta["weights"]), device="cuda:0")
     pol = DeviceSarlPolicy(net, z["action_space"], meta["gamma"])
     outs = env.alloc_step_outputs(("reward", "done", "info"))
+    agree = decided = 0
     for t in range(len(z["action"])):
         actions, values = pol.decide(env)
         torch.cuda.synchronize()
         v = values.cpu().numpy()
         assert (np.abs(v - v[0:1]) < 1e-5).all()
         if not np.isnan(z["values"][t]).any():
-            _check_values(v[0], z, t)
+            agree += _check_values(v[0], z, t)
+            decided += 1
         forced = torch.tensor(np.tile(z["action"][t], (E, 1)), dtype=torch.float64, device="cuda:0")
         env.step_device(outs, robot_action=forced, human_policy=_abi.HUMAN_CACHED)
         torch.cuda.synchronize()
         assert int(outs["info"][0]) == int(z["info"][t]), t
         np.testing.assert_allclose(float(outs["reward"][0]), z["reward"][t], atol=1e-9)
     assert int(z["info"][-1]) == _abi.INFO_REACH_GOAL
+    assert agree == decided, (agree, decided)  # every decision of the episode picks the reference's action
+    # the values above came from the HIP value-network kernels, not from a torch stand-in
+    assert net._native_blocks(), "the value network did not run on the MFMA blocks"
+    assert getattr(net, "native_forwards", 0) >= decided
+
+
+def _ragged_pool_decisions(make_env, device, check_rows):
+    """A scene pool whose scenes differ in size: after restarts the rows the policy masks with must be the
+    CURRENT scene's (read from the device state at every decision), and its values must equal the network
+    run on exactly the rows that exist."""
+    z = load("sarl_a5_baseline")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    params.time_limit = 1  # every env times out at step 4: restarts come quickly
+    E = 4
+    b = batch_from_init(z, copies=E)
+    pool = batch_from_init(z, copies=2 * E)
+    for c in range(2 * E):
+        pool.n_humans[c] = 5 - (c % 3)       # 5, 4, 3 humans
+        pool.px[c, pool.n_humans[c]:] = 0
+    env = make_env(params, E, b.N, b.S)
+    env.reset(b)
+    env.set_scene_pool(pool, stride=E)
+    env.use_torch_stream()
+    net = SarlValueNet.load(os.path.join(GOLDEN, "weights", meta["weights"]), device=device)
+    pol = DeviceSarlPolicy(net, z["action_space"], meta["gamma"])
+    outs = env.alloc_step_outputs(("reward", "done", "info"))
+    seen = set()
+    for t in range(14):
+        actions, values = pol.decide(env)
+        rows = check_rows(env)
+        assert env.ragged and pol.n_valid is not None
+        np.testing.assert_array_equal(pol.n_valid.cpu().numpy(), rows)
+        seen.update(rows.tolist())
+        # the masked batch forward == the network on the rows that exist, env by env
+        rr = pol._bufs["rows_rotated"]
+        for e in range(E):
+            alone = net.forward(rr[e, :, :int(rows[e])].contiguous()).to(torch.float64)
+            full = (values[e] - pol._bufs["reward"][e]) / (meta["gamma"] ** (params.time_step * pol._v_pref))
+            np.testing.assert_allclose(full.cpu().numpy(), alone.cpu().numpy(), atol=2e-5)
+        env.step_device(outs, robot_action=actions.contiguous(), human_policy=_abi.HUMAN_CACHED, flags=_abi.FLAG_AUTO_RESET)
+    assert seen == {3, 4, 5}  # the walk went through scenes of every size
+
+
+def test_ragged_pool_row_counts_follow_restarts_cpu():
+    from helpers import CpuDeviceEnv
+    _ragged_pool_decisions(CpuDeviceEnv, "cpu", lambda env: env._o.row_counts())
+
+
+@pytest.mark.gpu
+def test_ragged_pool_row_counts_follow_restarts_gpu():
+    from ebcsim.batched import BatchedEnv
+    _ragged_pool_decisions(lambda p, E, N, S: BatchedEnv(p, E, N, S), "cuda:0", lambda env: env.row_counts())
 
 
 @pytest.mark.gpu

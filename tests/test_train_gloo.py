@@ -293,3 +293,119 @@ def test_optimize_epoch_two_ranks_unequal_shards():
     assert np.isfinite(ret[0][0]) and np.isfinite(ret[1][0])
     for k, v in ret[0][1].items():
         torch.testing.assert_close(ret[1][1][k], v, atol=1e-7, rtol=1e-6)
+
+
+def test_replay_push_larger_than_capacity_keeps_pairs_consistent():
+    """collect_il pushes steps x E pairs in one call (4096 envs x 50 steps against the default capacity):
+    a ring keeps the newest `capacity` of them, each state still next to ITS value and row count."""
+    from ebcsim.train import DeviceReplay
+    cap, n, R, T = 16, 45, 3, 13
+    mem = DeviceReplay(cap, R, T, "cpu")
+    mem.push(torch.zeros(5, R, T), torch.zeros(5))      # something to overwrite, position 5
+    tag = torch.arange(n, dtype=torch.float32)
+    mem.push(tag[:, None, None].expand(n, R, T).clone(), tag, (tag % R + 1).to(torch.int64))
+    assert len(mem) == cap and mem.position == (5 + n) % cap and mem.ragged
+    assert sorted(mem.values.tolist()) == [float(v) for v in range(n - cap, n)]
+    assert torch.equal(mem.states[:, 0, 0], mem.values)                       # pair by pair
+    assert torch.equal(mem.n_valid, (mem.values % R + 1).to(torch.int64))
+    s, v, rows = mem.sample(8, torch.Generator().manual_seed(0), with_rows=True)
+    assert torch.equal(s[:, 0, 0], v) and torch.equal(rows, (v % R + 1).to(torch.int64))
+    # the newest item sits just before the write position, like after item-by-item pushes
+    assert mem.values[(mem.position - 1) % cap] == n - 1
+
+
+def _schedule_worker(rank, world, port, ret):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import json
+    import torch.distributed as dist
+    from ebcsim import _abi
+    from ebcsim.train import SarlModule, run_training
+    from helpers import CpuDeviceEnv, batch_from_init, load, params_of
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = load("sarl_a5_baseline")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    b = batch_from_init(z, copies=2)
+    # rank 0: the robot stands on its goal (one action: stay) -> every step is a ReachGoal episode: its
+    # shard has data after round 0.  rank 1: one action (0.15 m straight up per step), the robot 0.45 m
+    # below its goal (radius 0.2) -> ReachGoal at its second step: empty after round 0, filled after round 1.
+    gx, gy = b.robot[0, 5], b.robot[0, 6]
+    b.robot[:, 0], b.robot[:, 1] = gx, (gy if rank == 0 else gy - 0.45)
+    actions = np.array([[0.0, 0.0]]) if rank == 0 else np.array([[0.0, 0.6]])
+    env = CpuDeviceEnv(params, 2, b.N, b.S)
+    env.reset(b)
+    torch.manual_seed(1234 + rank)  # different constructors' draws: the schedule must broadcast rank 0's weights
+    model = SarlModule(**DIMS)
+    hist = run_training(env, model, actions, meta["gamma"], il_steps=0, train_iterations=3, steps_per_iteration=1,
+                        train_batches=2, batch_size=4, capacity=64, epsilon_start=0.0, epsilon_end=0.0,
+                        target_update_interval=2, generator=torch.Generator().manual_seed(rank), rank=rank)
+    ret[rank] = (hist["rl_loss"], {k: v.detach().clone() for k, v in model.named_parameters()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_training_two_ranks_fill_their_shards_at_different_rounds():
+    """rl/train.py:239-259 under two gloo ranks whose replay shards become non-empty in different rounds:
+    a round's optimizer steps (gradient all-reduces) are taken by both ranks or by neither, the replicas
+    start from rank 0's weights and stay identical."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_schedule_worker, args=(2, 29300 + os.getpid() % 500, ret), nprocs=2, join=True)
+    l0, l1 = ret[0][0], ret[1][0]
+    assert np.isnan(l0[0]) and np.isnan(l1[0])            # round 0: rank 1's shard is still empty -> nobody trains
+    assert np.isfinite(l0[1]) and np.isfinite(l1[1])      # round 1: both have data -> both train
+    assert np.isfinite(l0[2]) and np.isfinite(l1[2])
+    for k, v in ret[0][1].items():
+        torch.testing.assert_close(ret[1][1][k], v, atol=1e-7, rtol=1e-6)
+
+
+def _rl_memory_against_reference(make_env, device):
+    """explorer.py:171-184 + :82-92 (imitation_learning=False): one greedy SARL episode rolled by collect()
+    puts in the memory exactly the (state, value) pairs the reference's Explorer.update_memory put in its
+    ReplayMemory for the same episode (golden from the reference's own policy, explorer and memory)."""
+    import json
+    from ebcsim import _abi
+    from ebcsim.sarl import DeviceSarlPolicy, SarlValueNet
+    from ebcsim.train import DeviceReplay, EpisodeStore, collect, value_targets
+    from helpers import GOLDEN, batch_from_init, load, params_of
+    z, g = load("sarl_a5_baseline"), load("sarl_a5_rl_memory")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    b = batch_from_init(z, copies=1)
+    env = make_env(params, 1, b.N, b.S)
+    env.reset(b)
+    env.use_torch_stream()
+    net = SarlValueNet.load(os.path.join(GOLDEN, "weights", meta["weights"]), device=device)
+    policy = DeviceSarlPolicy(net, z["action_space"], float(g["gamma"]))
+    n = len(g["rl_value"])
+    assert n == len(z["action"])
+    mem = DeviceReplay(4 * n, env.R, env.T, device)
+    store = EpisodeStore(1, n + 2, env.R, env.T, device)
+    collect(env, policy, net, mem, n, float(g["gamma"]), epsilon=0.0, human_policy=_abi.HUMAN_ORCA, store=store)
+    assert len(mem) == n, (len(mem), n)  # the whole episode, pushed at its end (ReachGoal) and nothing else
+    np.testing.assert_allclose(mem.states[:n].cpu().numpy(), g["rl_state"], atol=1e-5)
+    np.testing.assert_allclose(mem.values[:n].cpu().numpy(), g["rl_value"], atol=5e-5)
+    # value_targets alone on the reference's own states: terminal -> reward, else reward + gamma_bar * V(next)
+    st = torch.from_numpy(g["rl_state"]).to(device)
+    rw = torch.from_numpy(g["reward"]).to(device)
+    done = torch.zeros(n, dtype=torch.uint8, device=device)
+    done[-1] = 1
+    nxt = torch.cat([st[1:], st[-1:]])
+    gb = float(g["gamma"]) ** (float(g["time_step"]) * float(g["robot_v_pref"]))
+    t = value_targets(rw, done, nxt, net, gb)
+    np.testing.assert_allclose(t.cpu().numpy(), g["rl_value"], atol=5e-5)
+    assert t[-1] == rw[-1]
+
+
+def test_rl_mode_memory_equals_the_reference_explorer_cpu():
+    from helpers import CpuDeviceEnv
+    _rl_memory_against_reference(CpuDeviceEnv, "cpu")
+
+
+@pytest.mark.gpu
+def test_rl_mode_memory_equals_the_reference_explorer_gpu():
+    from ebcsim.batched import BatchedEnv
+    _rl_memory_against_reference(lambda p, E, N, S: BatchedEnv(p, E, N, S), "cuda:0")
