@@ -127,10 +127,12 @@ class SARL(Policy):
             sweep = env.lookahead_all(self._action_rows)
             rows = torch.from_numpy(sweep["rows_rotated"][:, :sweep["n_rows"]]).to(self.device)
             net = self._value_net()
-            v, w = net.forward(rows, want_weights=True)
-            self._weights = w[-1].cpu().numpy()
+            # the attention weights of the network's last forward in the reference = of the last action
+            _, w = net.forward(rows[-1:], want_weights=True, exact=True)
+            self._weights = w[0].cpu().numpy()
             discount = pow(self.gamma, self.time_step * state.self_state.v_pref)
-            values = sweep["reward"] + discount * v.to("cpu", torch.float64).numpy()
+            reward = torch.from_numpy(np.ascontiguousarray(sweep["reward"], dtype=np.float64)).to(self.device)
+            values = net.action_values(rows[None], reward[None], discount)[0].cpu().numpy()
             self.action_values = [float(x) for x in values]
             if np.isnan(values).all():
                 raise ValueError("Value network is not well trained. ")

@@ -147,17 +147,43 @@ class SarlValueNet(object):
     def load(cls, path, device="cpu", **kw):
         return cls(torch.load(path, map_location="cpu"), device=device, **kw)
 
-    def forward(self, rows, n_valid=None, want_weights=False):
+    def forward(self, rows, n_valid=None, want_weights=False, exact=False):
         """rows [B, R, T] float32; n_valid [B] (rows that exist) or None = all -> values [B]
-        (with want_weights: (values, attention weights [B, R]), sarl.py:69-71)."""
+        (with want_weights: (values, attention weights [B, R]), sarl.py:69-71).  exact: plain float32
+        GEMMs instead of the split-bf16 matrix-core blocks (the arithmetic the reference's torch does)."""
         with torch.no_grad():
-            return self._forward(rows, n_valid, want_weights)
+            return self._forward(rows, n_valid, want_weights, exact)
 
-    def _forward(self, rows, n_valid=None, want_weights=False):
+    def action_values(self, rows, reward, discount, n_valid=None, refine=2, chunk_pairs=None):
+        """reward + discount * V(rows) for every candidate action (multi_human_rl.py:72-76): rows
+        [E, A, R, T] float32, reward [E, A] float64, n_valid [E] or None -> values [E, A] float64.
+        The blocks' values carry <= 1.5e-5 of split-bf16 error, and the reference's own best two actions are
+        sometimes closer than that (5.6e-6 in its golden episodes): the `refine` best candidates of every
+        env are therefore re-evaluated with plain float32 GEMMs (2 of 81 pairs: ~2 % more rows) before the
+        caller takes the argmax, so the DECISION is the float32 network's."""
+        E, A, R, T = rows.shape
+        step = E if not chunk_pairs else max(1, int(chunk_pairs) // A)
+        v = torch.empty((E, A), dtype=torch.float32, device=rows.device)
+        for e0 in range(0, E, step):
+            e1 = min(E, e0 + step)
+            nv = None if n_valid is None else n_valid[e0:e1].repeat_interleave(A)
+            v[e0:e1] = self.forward(rows[e0:e1].reshape(-1, R, T), nv).view(e1 - e0, A)
+        values = reward + discount * v.to(torch.float64)
+        k = min(int(refine), A)
+        if k > 0 and rows.is_cuda and self._native_blocks() is not None:
+            top = torch.topk(values, k, dim=1).indices                       # [E, k]
+            env = torch.arange(E, device=rows.device)[:, None].expand(E, k)
+            sel = rows[env, top].reshape(E * k, R, T)
+            nv = None if n_valid is None else n_valid.repeat_interleave(k)
+            exact = self.forward(sel, nv, exact=True).view(E, k).to(torch.float64)
+            values[env, top] = reward[env, top] + discount * exact
+        return values
+
+    def _forward(self, rows, n_valid=None, want_weights=False, exact=False):
         B, R, T = rows.shape
         rows = rows.to(getattr(self, "dtype", torch.float32))
         self_state = rows[:, 0, :self.self_state_dim]
-        nat = None if torch.is_grad_enabled() or not rows.is_cuda else self._native_blocks()
+        nat = None if torch.is_grad_enabled() or not rows.is_cuda or exact else self._native_blocks()
         if nat is not None:
             self.native_forwards = getattr(self, "native_forwards", 0) + 1  # tests assert the HIP path ran
             h1 = nat[0](rows.reshape(B * R, T), True)
@@ -219,7 +245,10 @@ class SarlValueNet(object):
 class DeviceSarlPolicy(object):
     """Greedy SARL decisions for a whole BatchedEnv (phase "test": no epsilon draw)."""
 
-    def __init__(self, net, actions, gamma, chunk_rows=1 << 21):
+    def __init__(self, net, actions, gamma, chunk_rows=1 << 21, refine=2):
+        """refine: candidates per env whose value is recomputed in plain float32 before the argmax
+        (SarlValueNet.action_values); 0 = the matrix-core values as they are."""
+        self.refine = int(refine)
         self.net = net
         self.actions_np = np.ascontiguousarray(actions, dtype=np.float64)
         self.gamma = float(gamma)
@@ -229,15 +258,9 @@ class DeviceSarlPolicy(object):
     def values_from(self, rows, reward, n_valid, dt, v_pref):
         """rows [E, A, R, T] float32, reward [E, A] float64 -> values [E, A] float64
         (multi_human_rl.py:72-76: reward + gamma^(dt * v_pref) * V)."""
-        E, A, R, T = rows.shape
-        per_env = A * R
-        step = max(1, self.chunk_rows // per_env)
-        out = torch.empty((E, A), dtype=torch.float32, device=rows.device)
-        for e0 in range(0, E, step):
-            e1 = min(E, e0 + step)
-            nv = None if n_valid is None else n_valid[e0:e1].repeat_interleave(A)
-            out[e0:e1] = self.net.forward(rows[e0:e1].reshape(-1, R, T), nv).view(e1 - e0, A)
-        return reward + (self.gamma ** (dt * v_pref)) * out.to(torch.float64)
+        R = rows.shape[2]
+        return self.net.action_values(rows, reward, self.gamma ** (dt * v_pref), n_valid, refine=self.refine,
+                                      chunk_pairs=max(1, self.chunk_rows // R))
 
     def decide(self, env, human_policy=_abi.HUMAN_ORCA):
         """env: BatchedEnv on this net's device.  Returns (actions [E, 2] float64 CUDA tensor,
