@@ -51,19 +51,20 @@ struct DevState {
   int *grid_scene;  // [E] pool slot whose occupancy grid env e uses (pool.grid is null when every map is free)
   double *robot;    // [E][9] FullState order
   double *robot_n;  // [E][9] the fused ORCA step writes the robots' next state here; the host then swaps the two
-  double *robot_pub;  // [E][9] the same values for the ROWS role, in a place no restart overwrites
   double *time;   // [E] global_time
   double *arrival;
   uint8_t *done;  // terminal flag of the last step
   double *hact;   // [E][N][2] human velocities: ebc_set_human_actions, or the look-ahead cache
-  // Mailboxes of the fused ORCA step (orca_step_kernel).  A word is data and "ready" flag at once:
-  // the producer stores a value that is never EMPTY, the consumer polls, takes it and puts EMPTY
-  // back, so every launch starts with every box empty.
-  unsigned long long *vel_state;  // [E][N] ORCA velocity (two floats) for the STATE role
-  unsigned long long *vel_rows;   // [E][N] the same for the ROWS role
-  unsigned *env_done;             // [E] ENV -> STATE: 1 + done
-  unsigned *rows_loaded;          // [E] ROWS -> STATE: pre-step state has been read (1)
-  unsigned *robot_ready;          // [E] ENV -> ROWS: robot_pub[e] holds this step's result (= the launch's epoch; never reset)
+  // Mailboxes of the fused ORCA step (orca_step_kernel).  Every word carries the EPOCH of the launch that
+  // wrote it (a counter that never repeats within 2^32 launches and is never 0): a consumer polls until the
+  // tag is this launch's, nobody ever empties a box, several roles may read the same one, and a box left
+  // over from an aborted launch cannot be mistaken for a fresh one.  (Round 1 kept data + EMPTY in one
+  // 8-byte word, one box per consumer, re-emptied by it: four 8-byte fabric writes per human and step
+  // instead of one 16-byte one.)
+  uint4 *vel;                     // [E][N] ORCA -> STATE, ROWS: {vx bits, epoch, vy bits, epoch}, one 16-byte store
+  unsigned long long *env_done;   // [E] ENV -> STATE: epoch << 32 | 1 + done
+  unsigned *rows_loaded;          // [E] ROWS -> STATE: = epoch once the pre-step state AND the robot's next state are in registers
+  unsigned *robot_ready;          // [E] ENV -> ROWS: = epoch once robot_n[e] holds this step's result
   unsigned *fault;                // [1] a poll gave up (protocol broken); ebc_synchronize reports it
   ScenePool pool;  // where auto-reset takes an env's next scene from
   // what rvo2 would hold for the current state (float), one 32-byte record per human slot:
@@ -75,7 +76,6 @@ struct DevState {
   unsigned n_magic, n_shift;
 };
 
-#define EBC_SLOT_EMPTY 0xFFFFFFFFFFFFFFFFull  // two all-ones NaNs: no arithmetic result
 #ifndef EBC_SPIN_LIMIT
 #define EBC_SPIN_LIMIT (1u << 22)               // polls before a consumer gives up (~1 s)
 #endif
@@ -325,6 +325,19 @@ __device__ __forceinline__ void pin(Tp &x) {
   asm volatile("" : "+v"(x));
 }
 
+// A reference to an object in LDS whose reads the compiler cannot move above this point.  The argument
+// block is read from LDS (below); left alone the compiler hoists those ds_reads to the top of the wave —
+// and then SPILLS the values to scratch when they are only needed at its end (found in the ENV role: 14
+// spilled registers were the time step, grid pointer, global time, ... read early, used late; any scratch
+// use costs every wave of the launch its scratch set-up).
+template <typename Tp>
+__device__ __forceinline__ const Tp &read_late(const Tp &x) {
+  typedef const Tp __attribute__((address_space(3))) *LdsPtr;
+  unsigned off = (unsigned)(size_t)(LdsPtr)&x;  // the 32-bit LDS address goes through the asm, not a pointer
+  asm volatile("" : "+v"(off));
+  return *(const Tp *)(LdsPtr)(size_t)off;
+}
+
 // The kernel-argument block lives in (device) memory that is not cached like ordinary data: every
 // s_load of it that the compiler places in the middle of the service wave's dependent chain is a
 // memory round trip (the argument structs are ~700 B, far more than the SGPR file keeps live, so
@@ -485,15 +498,26 @@ __device__ __forceinline__ CommitAddr commit_addr(const DevState &s, const StepI
   return a;
 }
 
-// wave-wide: returns once every lane with `need` has found its word non-empty (or gave up)
-template <typename W>
-__device__ __forceinline__ W mailbox_wait(W *box, bool need, W empty, unsigned *fault) {
-  W v = empty;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte device-scope (sc1: L2-served, never from this CU's L1) load / store of a mailbox granule.  The load
+// waits for its data inside the statement: the compiler does not track loads issued by asm.
+__device__ __forceinline__ u32x4 load16_device(const uint4 *box) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(box) : "memory");
+  return v;
+}
+__device__ __forceinline__ void store16_device(uint4 *box, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(box), "v"(v) : "memory");
+}
+// wave-wide: returns once every lane with `need` has found its velocity word tagged with this launch's
+// epoch in both halves (or gave up)
+__device__ __forceinline__ u32x4 velocity_wait(const uint4 *box, bool need, unsigned epoch, unsigned *fault) {
+  u32x4 v = {0u, 0u, 0u, 0u};
   bool waiting = need;
   for (unsigned spins = 0;; ++spins) {
     if (waiting) {
-      v = __hip_atomic_load(box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      waiting = v == empty;
+      v = load16_device(box);
+      waiting = v.y != epoch || v.w != epoch;
     }
     if (!__any(waiting)) break;
     if (spins > EBC_SPIN_LIMIT) {
@@ -504,7 +528,7 @@ __device__ __forceinline__ W mailbox_wait(W *box, bool need, W empty, unsigned *
   }
   return v;
 }
-// the same for a box that holds the launch's epoch when ready (several readers, never emptied)
+// the same for a box that holds the launch's epoch when ready
 __device__ __forceinline__ void mailbox_wait_epoch(unsigned *box, bool need, unsigned epoch, unsigned *fault) {
   bool waiting = need;
   for (unsigned spins = 0;; ++spins) {
@@ -521,9 +545,9 @@ template <typename W>
 __device__ __forceinline__ void mailbox_put(W *box, W v) {
   __hip_atomic_store(box, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void unpack_velocity(unsigned long long v, double &ax, double &ay) {
-  ax = (double)__uint_as_float((unsigned)v);  // getAgentVelocity -> Python float
-  ay = (double)__uint_as_float((unsigned)(v >> 32));
+__device__ __forceinline__ void unpack_velocity(u32x4 v, double &ax, double &ay) {
+  ax = (double)__uint_as_float(v.x);  // getAgentVelocity -> Python float
+  ay = (double)__uint_as_float(v.z);
 }
 
 // The robot's action for this step (its policy, or the caller's) — env.py:388-392.
@@ -560,15 +584,30 @@ __device__ __forceinline__ void robot_advance(const EbcParams &p, double *rb, do
 struct EnvScratch {  // LDS of one service_env wave
   double cand[3][EBC_WAVE];  // per collision class: this lane's distance, if it counts
   double ract[EBC_WAVE][2];  // the envs' robot actions
+  double gtime[EBC_WAVE];    // per env: global time, parked from its early load to the reward at the end
+  int n[EBC_WAVE];           // per env: its number of humans, parked for the leader's walk over them
 };
-__device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s, const StepIO &io,
+__device__ __forceinline__ int service_env(const EbcParams &p_early, const DevState &s_early, const StepIO &io_early,
                                            const LaneMap &m, const HumanRegs &h, double rb[9],
-                                           double gtime, int lane, EnvScratch &X, unsigned epoch = 0) {
+                                           double gtime, int lane, EnvScratch &X, unsigned epoch = 0, int e0 = 0) {
+  int coll_t[3], grid_slot;
+  {
+  const EbcParams &p = p_early;
+  const DevState &s = s_early;
+  const StepIO &io = io_early;
   double (&sh_cand)[3][EBC_WAVE] = X.cand;
   double (&sh_ract)[EBC_WAVE][2] = X.ract;
   const double dt = p.time_step;
-  int grid_slot = (m.leader && s.pool.grid) ? s.grid_scene[m.ee] : 0;
+  grid_slot = (m.leader && s.pool.grid) ? s.grid_scene[m.ee] : 0;
   pin(grid_slot);
+  const int epb_env = EBC_WAVE / s.N;                     // envs per wave
+  const bool coalesce = 9 * epb_env <= 3 * EBC_WAVE;      // their robots fit the distance scratch (N >= 3)
+  if (m.leader) {
+    X.gtime[m.el] = gtime;
+    X.n[m.el] = m.n;
+  }
+  // which lanes carry a human, as a wave mask in scalar registers: m.n need not stay in a vector register
+  const unsigned long long active_mask = __ballot(m.active);
   if (m.leader) {
     double a0, a1;
     if (io.robot_policy == EBC_ROBOT_LINEAR) {
@@ -585,21 +624,30 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
 #pragma unroll
       for (int c = 0; c < 9; ++c) rn[c] = rb[c];
       robot_advance(p, rn, a0, a1);
-      // Device-scope stores go through to memory; the flag is stored (below, after the distance
-      // work) once they have been acknowledged.  (An agent-scope release FENCE would do, but on this
-      // part it writes back the whole L2 of the XCD: it doubled the step time.)
-      // Two copies: robot_n is what the next step reads (a restart overwrites it later in this
-      // launch, so this store must already be in memory by then: device scope as well); robot_pub
-      // is what the ROWS role builds this step's observation frame from.
-      double *o = s.robot_n + m.ee * 9, *o2 = s.robot_pub + m.ee * 9;
+      // The robots' next states leave as ONE run of device-scope stores for the whole wave (lane = (env, field):
+      // the envs of a wave are consecutive, so the run is contiguous) instead of nine 8-byte fabric writes
+      // per env from the leader lanes: staged through the distance scratch, which is not in use yet.
+      // robot_n is what the ROWS role builds this step's observation frame from (after robot_ready) and
+      // what the next step reads; a restart overwrites it later in this launch — only after ROWS has it
+      // (rows_loaded).  (An agent-scope release FENCE instead of device-scope stores writes back the whole
+      // L2 of the XCD on this part: it doubled the step time.)
+      if (coalesce) {
 #pragma unroll
-      for (int c = 0; c < 9; ++c) {
-        __hip_atomic_store(o + c, rn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(o2 + c, rn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int c = 0; c < 9; ++c) (&sh_cand[0][0])[m.el * 9 + c] = rn[c];
+      } else {
+        double *o = s.robot_n + m.ee * 9;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) __hip_atomic_store(o + c, rn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
   wave_sync();
+  if (epoch && coalesce) {
+    const int envs_here = min(epb_env, s.E - e0);
+    for (int q = lane; q < 9 * envs_here; q += EBC_WAVE)
+      __hip_atomic_store(s.robot_n + (size_t)e0 * 9 + q, (&sh_cand[0][0])[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wave_sync();  // the scratch is the distance scratch again
+  }
   const double a0 = sh_ract[m.env_ok ? m.el : 0][0], a1 = sh_ract[m.env_ok ? m.el : 0][1];
   double rvx, rvy;
   if (p.robot_kinematics == EBC_HOLONOMIC) {
@@ -612,16 +660,17 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
   // ordered per-type reduction with break at the first hit (env.py:303-313), without the serial
   // walk: per type, the first colliding human of the env comes out of a ballot; a human counts
   // for the type's minimum distance when it lies before that one
-  const double d = m.active ? closest_dist(h.px, h.py, h.vx, h.vy, h.rad, rb[0], rb[1], rb[4], rvx, rvy, dt) : 0.0;
-  const bool hit = m.active && d < 0;
+  const bool active = (active_mask >> lane) & 1;
+  const double dt_now = read_late(p_early).time_step;
+  const double d = active ? closest_dist(h.px, h.py, h.vx, h.vy, h.rad, rb[0], rb[1], rb[4], rvx, rvy, dt_now) : 0.0;
+  const bool hit = active && d < 0;
   const int base = lane - m.i;  // first lane of this env
-  int coll_t[3];
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const unsigned long long hm = (__ballot(hit && h.type == t) >> base) & (s.N >= 64 ? ~0ull : ((1ull << s.N) - 1));
     const int first = hm ? __ffsll((long long)hm) - 1 : s.N;
     coll_t[t] = hm != 0;
-    sh_cand[t][lane] = (m.active && h.type == t && !hit && m.i < first) ? d : INFINITY;
+    sh_cand[t][lane] = (active && h.type == t && !hit && m.i < first) ? d : INFINITY;
   }
   wave_sync();
   EBC_MARK(2);
@@ -629,10 +678,20 @@ __device__ __forceinline__ int service_env(const EbcParams &p, const DevState &s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (m.leader) mailbox_put(s.robot_ready + m.ee, epoch);
   }
+  }
   if (!m.leader) return 0;
+  const double a0 = X.ract[m.el][0], a1 = X.ract[m.el][1];
+  const double dt = read_late(p_early).time_step;
+  double (&sh_cand)[3][EBC_WAVE] = X.cand;
+  // the leader's tail reads its arguments HERE (read_late), not at the top of the wave
+  const EbcParams &p = read_late(p_early);
+  const DevState &s = read_late(s_early);
+  const StepIO &io = read_late(io_early);
+  gtime = read_late(X).gtime[m.el];
+  const int n_env = read_late(X).n[m.el];
   double dm0 = INFINITY, dm1 = INFINITY, dm2 = INFINITY;
   const int c0 = coll_t[0], c1 = coll_t[1], c2 = coll_t[2];
-  for (int q = 0; q < m.n; ++q) {  // independent loads: no branch between them
+  for (int q = 0; q < n_env; ++q) {  // independent loads: no branch between them
     const double d0 = sh_cand[0][lane + q], d1 = sh_cand[1][lane + q], d2 = sh_cand[2][lane + q];
     dm0 = d0 < dm0 ? d0 : dm0;
     dm1 = d1 < dm1 ? d1 : dm1;
@@ -870,10 +929,11 @@ __global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState
 //
 //   ENV    service_env (6 envs per wave at N = 10): the robot side of the step, reward / done /
 //          info.  The longest dependent chain, so these blocks come first.    -> env_done
-//   ORCA   64 / GS humans per wave                                            -> vel_state, vel_rows
+//   ORCA   64 / GS humans per wave                                            -> vel
 //   ROWS   lane = observation row slot: reads the pre-step state, tells STATE so (rows_loaded),
-//          takes the human's velocity from vel_rows, emits the raw and the rotated row
-//   STATE  lane = human slot: takes vel_state and env_done, moves the humans, writes the state
+//          takes the robot's next state (robot_n, after robot_ready) and the human's velocity (vel),
+//          emits the raw and the rotated row
+//   STATE  lane = human slot: takes vel and env_done, moves the humans, writes the state
 //          and float tile of the next step (or the restart scene)
 //
 // Everything in a step is local to an env, so the roles meet through per-env / per-human mailbox
@@ -915,13 +975,12 @@ __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &
   load_robot(s, m, rb);
   double gtime = m.env_ok ? s.time[m.ee] : 0.0;
   HumanRegs h = load_human(s, m);
-  unsigned *done_box = s.env_done + m.ee;
-  pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type); pin(gtime); pin(done_box);
+  pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type); pin(gtime);
 #pragma unroll
   for (int q = 0; q < 9; ++q) pin(rb[q]);
   EBC_MARK(0);
-  const int done = service_env(p, s, io, m, h, rb, gtime, lane, L.env, epoch);
-  if (m.leader) mailbox_put(done_box, 1u + (unsigned)done);
+  const int done = service_env(p, s, io, m, h, rb, gtime, lane, L.env, epoch, block * epb);
+  if (m.leader) mailbox_put(read_late(s).env_done + m.ee, ((unsigned long long)epoch << 32) | (1u + (unsigned)done));
 }
 
 // Have a kernel argument in a scalar register HERE.  The compiler otherwise loads each field where
@@ -934,10 +993,9 @@ __device__ __forceinline__ void sreg(const Tp &x) {
 
 // ---- ORCA
 template <int GS>
-__device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s, const OrcaHot &hot,
-                                          unsigned long long *vel_state, unsigned long long *vel_rows,
-                                          unsigned char *scratch, unsigned block, bool rows, int lane) {
-  // `hot`, vel_state, vel_rows: preloaded kernel arguments; the rest is asked for now, all at once
+__device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s, const OrcaHot &hot, uint4 *vel, unsigned epoch,
+                                          unsigned char *scratch, unsigned block, int lane) {
+  // `hot`, vel, epoch: preloaded kernel arguments; the rest is asked for now, all at once
   sreg(s.robot); sreg(s.range_sq); sreg(s.inv_time_horizon); sreg(s.inv_time_step);
   sreg(p.robot_visible); sreg(p.orca_max_neighbors); sreg(p.orca_safety_space);
   constexpr int HPW = EBC_WAVE / GS;
@@ -953,11 +1011,9 @@ __device__ __forceinline__ void orca_role(const EbcParams &p, const DevState &s,
 #ifdef EBC_WAVE_TRACE  // measurement / test build only: one producer "forgets" its hand-off (tests the give-up path)
   if (h_ok && (int)hh == g_withhold_human) return;
 #endif
-  if (h_ok && j == 0) {
-    unsigned long long v = human_ok ? ((unsigned long long)__float_as_uint(oy) << 32) | __float_as_uint(ox) : 0ull;
-    if (v == EBC_SLOT_EMPTY) v = 0x7FC000007FC00000ull;  // not an arithmetic result; keeps the protocol total
-    mailbox_put(vel_state + hh, v);
-    if (rows) mailbox_put(vel_rows + hh, v);  // a box nobody empties would hold a stale velocity
+  if (h_ok && j == 0) {  // one 16-byte device-scope store: the velocity, tagged with this launch's epoch in both halves
+    const u32x4 w = {human_ok ? __float_as_uint(ox) : 0u, epoch, human_ok ? __float_as_uint(oy) : 0u, epoch};
+    store16_device(vel + hh, w);
   }
 }
 
@@ -995,24 +1051,24 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
     } else if (env_ok) {
       opx = s.spx[q]; opy = s.spy[q]; orad = s.sradius[q]; otype = EBC_ADULT_STATIC;
     }
-    unsigned long long *vbox = s.vel_rows + k;
+    const uint4 *vbox = s.vel + k;
     pin(opx); pin(opy); pin(orad); pin(otype); pin(vbox); pin(n); pin(ns);
-    // every pre-step value this env's rows need is in registers: STATE may overwrite the state
-    if (env_ok && slot + stride >= R && first == 0) mailbox_put(s.rows_loaded + ee, 1u);
     if (slot == first) {
       // the robot's next state: the ENV role publishes it early in its run (service_env)
       mailbox_wait_epoch(s.robot_ready + ee, env_ok, epoch, s.fault);
       double rb[9];  // device-scope loads, issued after the flag was seen: they do not come from a stale cache line
 #pragma unroll
       for (int c = 0; c < 9; ++c)
-        rb[c] = env_ok ? __hip_atomic_load(s.robot_pub + ee * 9 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        rb[c] = env_ok ? __hip_atomic_load(s.robot_n + ee * 9 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
       f = rot_frame(rb, p.rotate_unicycle);
       pin(f.px); pin(f.py); pin(f.dg);
     }
+    // every pre-step value this env's rows need AND the robot's next state are in registers: STATE may
+    // overwrite the state, and (restart) robot_n
+    if (env_ok && slot + stride >= R && first == 0) mailbox_put(s.rows_loaded + ee, epoch);
     const bool valid = human ? slot < n : slot - N < ns;
     const int row = human ? (valid ? slot : ns + slot) : (valid ? n + slot - N : slot);
-    const unsigned long long v = mailbox_wait(vbox, env_ok && human, (unsigned long long)EBC_SLOT_EMPTY, s.fault);
-    if (env_ok && human) mailbox_put(vbox, (unsigned long long)EBC_SLOT_EMPTY);
+    const u32x4 v = velocity_wait(vbox, env_ok && human, epoch, s.fault);
     if (env_ok) {
       if (human && valid) {  // Agent.step (agent.py:202-211)
         double ax, ay;
@@ -1048,7 +1104,7 @@ __device__ __forceinline__ void rows_role(const EbcParams &p_in, const DevState 
 
 // ---- STATE
 __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in,
-                                           RoleLds &L, int block, bool wait_rows, int lane) {
+                                           RoleLds &L, int block, bool wait_rows, unsigned epoch, int lane) {
   stage_args(&L.args.p, p_in, lane);
   stage_args(&L.args.s, s_in, lane);
   stage_args(&L.args.io, io_in, lane);
@@ -1063,8 +1119,9 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   StepIO io_state = io;  // no observation rows here: CommitPre's static-row preloads stay empty
   io_state.ob = nullptr;
   io_state.obs_rotated = nullptr;
-  unsigned long long *vbox = s.vel_state + m.k;
-  unsigned *done_box = s.env_done + m.ee, *loaded_box = s.rows_loaded + m.ee;
+  const uint4 *vbox = s.vel + m.k;
+  unsigned long long *done_box = s.env_done + m.ee;
+  unsigned *loaded_box = s.rows_loaded + m.ee;
   // The restart scene while there is nothing else to do (behind the cursor when a custom pool is
   // installed), its preferred velocity (worked out when the pool was uploaded) and, parked in LDS,
   // the restart robot.
@@ -1092,18 +1149,23 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   // wait for this wave's humans (every ORCA group of these envs has then read the tile and the
   // robot), for the envs' robot-side result, and for the ROWS waves to have read the old state
   // (one loop for the three boxes: a poll is a memory round trip, three in a row were 2 us of the step)
-  unsigned long long v = EBC_SLOT_EMPTY;
+  u32x4 v = {0u, 0u, 0u, 0u};
   unsigned d = 0;
   {
     bool wv = m.env_ok, wd = m.env_ok, wr = m.env_ok && wait_rows;
     for (unsigned spins = 0;; ++spins) {
-      unsigned r = 1;
-      if (wv) v = __hip_atomic_load(vbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (wd) d = __hip_atomic_load(done_box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long dw = 0;
+      unsigned r = epoch;
+      // the two small loads first; the 16-byte load's wait (inside load16_device) then covers all three
+      if (wd) dw = __hip_atomic_load(done_box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (wr) r = __hip_atomic_load(loaded_box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      wv = wv && v == EBC_SLOT_EMPTY;
-      wd = wd && d == 0;
-      wr = wr && r == 0;
+      if (wv) v = load16_device(vbox);
+      wv = wv && (v.y != epoch || v.w != epoch);
+      if (wd && (unsigned)(dw >> 32) == epoch) {
+        d = (unsigned)dw;
+        wd = false;
+      }
+      wr = wr && r != epoch;
       if (!__any(wv || wd || wr)) break;
       if (spins > EBC_SPIN_LIMIT) {
         if (wv || wd || wr) atomicOr(s.fault, 1u);
@@ -1114,11 +1176,6 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
   }
   EBC_MARK(1);
   if (!m.env_ok) return;
-  mailbox_put(vbox, (unsigned long long)EBC_SLOT_EMPTY);
-  if (m.leader) {
-    mailbox_put(done_box, 0u);
-    if (wait_rows) mailbox_put(loaded_box, 0u);
-  }
   const bool restore = io.auto_reset && d == 2u;
   const double tnew = gtime + p.time_step;
   const int N = s.N, S = s.S;
@@ -1223,7 +1280,7 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
     // 14 dwords the wave finds in scalar registers when it starts (kernarg preload): its role and, for
     // an ORCA wave, everything up to its first vector load
     unsigned env_blocks, unsigned orca_blocks, int hot_E, int hot_N, unsigned hot_magic, unsigned hot_shift,
-    const float4 *hot_tile, const int *hot_n_humans, unsigned long long *hot_vel_state, unsigned long long *hot_vel_rows,
+    const float4 *hot_tile, const int *hot_n_humans, uint4 *hot_vel, unsigned hot_epoch, unsigned hot_pad,
     EbcParams p_in, DevState s_in, StepIO io_in, StepGrid g) {
   const WaveTrace wt(2);
   constexpr size_t LDS = ((sizeof(RoleLds) > (size_t)OrcaLds<GS>::BYTES ? sizeof(RoleLds) : (size_t)OrcaLds<GS>::BYTES) + 15) / 16 * 16;
@@ -1244,7 +1301,7 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
   b -= env_blocks;
   if (b < orca_blocks) {
     const OrcaHot hot{hot_E, hot_N, hot_magic, hot_shift, hot_tile, hot_n_humans};
-    if (EBC_ROLE_MASK & 2) orca_role<GS>(p_in, s_in, hot, hot_vel_state, hot_vel_rows, lds, b, g.rows_blocks != 0, lane);
+    if (EBC_ROLE_MASK & 2) orca_role<GS>(p_in, s_in, hot, hot_vel, hot_epoch, lds, b, lane);
     return;
   }
   b -= orca_blocks;
@@ -1253,7 +1310,7 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
     return;
   }
   b -= g.rows_blocks;
-  if (EBC_ROLE_MASK & 8) state_role(p_in, s_in, io_in, L, (int)b, g.rows_blocks != 0, lane);
+  if (EBC_ROLE_MASK & 8) state_role(p_in, s_in, io_in, L, (int)b, g.rows_blocks != 0, g.epoch, lane);
 }
 
 // Observation rows that exist per env (humans + static obstacles as pedestrians, env.py:381-382, :457-458):

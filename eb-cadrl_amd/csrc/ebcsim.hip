@@ -83,10 +83,11 @@ int ensure_stage(Handle *h, size_t bytes) {
 // Mailboxes as every launch expects to find them (empty), and the fault word cleared.
 int arm_mailboxes(Handle *h) {
   const size_t EN = (size_t)h->s.E * h->s.N, E = (size_t)h->s.E;
-  HIP_TRY(hipMemsetAsync(h->s.vel_state, 0xFF, EN * 8, h->stream));
-  HIP_TRY(hipMemsetAsync(h->s.vel_rows, 0xFF, EN * 8, h->stream));
-  HIP_TRY(hipMemsetAsync(h->s.env_done, 0, E * 4, h->stream));
+  // epoch tags of 0 match no launch (the epoch counter skips 0)
+  HIP_TRY(hipMemsetAsync(h->s.vel, 0, EN * 16, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.env_done, 0, E * 8, h->stream));
   HIP_TRY(hipMemsetAsync(h->s.rows_loaded, 0, E * 4, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.robot_ready, 0, E * 4, h->stream));
   HIP_TRY(hipMemsetAsync(h->s.fault, 0, 4, h->stream));
   return EBC_OK;
 }
@@ -190,11 +191,11 @@ int launch_orca_step_gs(Handle *h, const StepIO &io, unsigned blocks, const ebc:
   if (h->T == 17)
     hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 17>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream,
                        g.env_blocks, g.orca_blocks, h->s.E, h->s.N, h->s.n_magic, h->s.n_shift, (const float4 *)h->s.tile,
-                       (const int *)h->s.n_humans, h->s.vel_state, h->s.vel_rows, h->p, h->s, io, g);
+                       (const int *)h->s.n_humans, h->s.vel, g.epoch, 0u, h->p, h->s, io, g);
   else
     hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 13>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream,
                        g.env_blocks, g.orca_blocks, h->s.E, h->s.N, h->s.n_magic, h->s.n_shift, (const float4 *)h->s.tile,
-                       (const int *)h->s.n_humans, h->s.vel_state, h->s.vel_rows, h->p, h->s, io, g);
+                       (const int *)h->s.n_humans, h->s.vel, g.epoch, 0u, h->p, h->s, io, g);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
@@ -211,7 +212,7 @@ int launch_orca_step(Handle *h, const StepIO &io) {
   g.rows_blocks = (io.ob || io.obs_rotated) ? (unsigned)((h->s.E + g.rows_epw - 1) / g.rows_epw) : 0u;
   const unsigned long long blocks = 2ull * g.env_blocks + g.orca_blocks + g.rows_blocks;
   if (blocks >= 2147483648ull) return fail(EBC_ERR_UNSUPPORTED, "ORCA step grid >= 2^31 workgroups");
-  if (++h->epoch == 0) h->epoch = 1;  // robot_ready boxes hold the epoch of the launch that filled them
+  if (++h->epoch == 0) h->epoch = 1;  // every mailbox word is tagged with the epoch of the launch that wrote it; 0 = never
   g.epoch = h->epoch;
   g.total = (unsigned)blocks;
   const int rc = launch_orca_step_sized(h, io, blocks, g);
@@ -448,12 +449,10 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
 #define A_(field, cnt) if (rc == EBC_OK) rc = dev_alloc(h, &s.field, (cnt))
   A_(n_humans, n_envs); A_(px, EN); A_(py, EN); A_(vx, EN); A_(vy, EN); A_(gx, EN); A_(gy, EN);
   A_(radius, EN); A_(v_pref, EN); A_(type, EN); A_(n_static, n_envs); A_(spx, ES); A_(spy, ES);
-  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(robot_pub, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN);
+  A_(sradius, ES); A_(robot, (size_t)n_envs * 9); A_(robot_n, (size_t)n_envs * 9); A_(time, n_envs); A_(arrival, EN);
   A_(tile, EN * 2);
   A_(done, n_envs); A_(hact, EN * 2);
-  A_(vel_state, EN); A_(vel_rows, EN); A_(env_done, n_envs); A_(rows_loaded, n_envs); A_(robot_ready, n_envs); A_(fault, 1);
-  if (rc == EBC_OK && (hipMemset(s.vel_state, 0xFF, EN * 8) != hipSuccess || hipMemset(s.vel_rows, 0xFF, EN * 8) != hipSuccess))
-    rc = EBC_ERR_DEVICE;
+  A_(vel, EN); A_(env_done, n_envs); A_(rows_loaded, n_envs); A_(robot_ready, n_envs); A_(fault, 1);  // zeroed: tag 0 = no launch
 #undef A_
   if (rc == EBC_OK) rc = dev_alloc(h, &s.pool.cursor, n_envs);
   if (rc == EBC_OK) rc = dev_alloc(h, &s.grid_scene, n_envs);

@@ -19,8 +19,11 @@ def main(path, pattern=""):
         elif cur is not None and ":" in t:
             k, v = t.split(":", 1)
             cur[k.strip()] = v.strip()
-    names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True,
-                           text=True).stdout.splitlines()
+    if not rows:
+        print("no kernels in %s" % path)
+        return
+    names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True,
+                           stdin=subprocess.DEVNULL).stdout.splitlines()
     print("%-64s %5s %5s %5s %7s %6s %5s %7s" % ("kernel", "SGPR", "VGPR", "AGPR", "scratch", "spillV", "occ", "LDS"))
     for r, n in zip(rows, names):
         n = re.sub(r"\(.*", "", n).replace("ebc::", "").replace("void ", "")
