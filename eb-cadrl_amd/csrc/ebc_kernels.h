@@ -501,13 +501,27 @@ __device__ __forceinline__ CommitAddr commit_addr(const DevState &s, const StepI
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // 16-byte device-scope (sc1: L2-served, never from this CU's L1) load / store of a mailbox granule.  The load
 // waits for its data inside the statement: the compiler does not track loads issued by asm.
+#ifndef EBC_VEL_STORE_SCOPE
+#define EBC_VEL_STORE_SCOPE "sc1"
+#endif
 __device__ __forceinline__ u32x4 load16_device(const uint4 *box) {
   u32x4 v;
+#ifdef EBC_VEL_8B  // experiment: the granule as two 8-byte device-scope atomics
+  const unsigned long long a = __hip_atomic_load((const unsigned long long *)box, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load((const unsigned long long *)box + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.x = (unsigned)a; v.y = (unsigned)(a >> 32); v.z = (unsigned)b; v.w = (unsigned)(b >> 32);
+#else
   asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(box) : "memory");
+#endif
   return v;
 }
 __device__ __forceinline__ void store16_device(uint4 *box, u32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(box), "v"(v) : "memory");
+#ifdef EBC_VEL_8B
+  __hip_atomic_store((unsigned long long *)box, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((unsigned long long *)box + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off " EBC_VEL_STORE_SCOPE ::"v"(box), "v"(v) : "memory");
+#endif
 }
 // wave-wide: returns once every lane with `need` has found its velocity word tagged with this launch's
 // epoch in both halves (or gave up)
@@ -581,14 +595,20 @@ __device__ __forceinline__ void robot_advance(const EbcParams &p, double *rb, do
 // `epoch` != 0 (fused ORCA step): the leader publishes the robot's next state in s.robot_n as soon
 // as the action is known — the ROWS role builds the observation frame from it long before the
 // collision / reward work below is done.
+#define EBC_ROBOT_STAGE 21  // robots (9 doubles each) the distance scratch stages at once: 3 * 64 / 9
 struct EnvScratch {  // LDS of one service_env wave
   double cand[3][EBC_WAVE];  // per collision class: this lane's distance, if it counts
   double ract[EBC_WAVE][2];  // the envs' robot actions
   double gtime[EBC_WAVE];    // per env: global time, parked from its early load to the reward at the end
   int n[EBC_WAVE];           // per env: its number of humans, parked for the leader's walk over them
 };
+// humans(): the lane's human (position, velocity, radius, type) — asked for AFTER the robot's action has been
+// worked out and published.  The fused step's ENV role loads its humans only then: double-precision
+// atan2 / sin / cos beside ten live human registers did not fit its 80-register budget (spills), and the
+// ENV waves are not what the launch waits for; the one-wave step kernel hands over preloaded registers.
+template <typename Humans>
 __device__ __forceinline__ int service_env(const EbcParams &p_early, const DevState &s_early, const StepIO &io_early,
-                                           const LaneMap &m, const HumanRegs &h, double rb[9],
+                                           const LaneMap &m, Humans humans, double rb[9],
                                            double gtime, int lane, EnvScratch &X, unsigned epoch = 0, int e0 = 0) {
   int coll_t[3], grid_slot;
   {
@@ -601,7 +621,6 @@ __device__ __forceinline__ int service_env(const EbcParams &p_early, const DevSt
   grid_slot = (m.leader && s.pool.grid) ? s.grid_scene[m.ee] : 0;
   pin(grid_slot);
   const int epb_env = EBC_WAVE / s.N;                     // envs per wave
-  const bool coalesce = 9 * epb_env <= 3 * EBC_WAVE;      // their robots fit the distance scratch (N >= 3)
   if (m.leader) {
     X.gtime[m.el] = gtime;
     X.n[m.el] = m.n;
@@ -631,10 +650,10 @@ __device__ __forceinline__ int service_env(const EbcParams &p_early, const DevSt
       // what the next step reads; a restart overwrites it later in this launch — only after ROWS has it
       // (rows_loaded).  (An agent-scope release FENCE instead of device-scope stores writes back the whole
       // L2 of the XCD on this part: it doubled the step time.)
-      if (coalesce) {
+      if (m.el < EBC_ROBOT_STAGE) {
 #pragma unroll
         for (int c = 0; c < 9; ++c) (&sh_cand[0][0])[m.el * 9 + c] = rn[c];
-      } else {
+      } else {  // N <= 2: more envs per wave than the scratch stages at once (rare shape)
         double *o = s.robot_n + m.ee * 9;
 #pragma unroll
         for (int c = 0; c < 9; ++c) __hip_atomic_store(o + c, rn[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -642,12 +661,13 @@ __device__ __forceinline__ int service_env(const EbcParams &p_early, const DevSt
     }
   }
   wave_sync();
-  if (epoch && coalesce) {
-    const int envs_here = min(epb_env, s.E - e0);
+  if (epoch) {
+    const int envs_here = min(min(epb_env, EBC_ROBOT_STAGE), s.E - e0);
     for (int q = lane; q < 9 * envs_here; q += EBC_WAVE)
       __hip_atomic_store(s.robot_n + (size_t)e0 * 9 + q, (&sh_cand[0][0])[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     wave_sync();  // the scratch is the distance scratch again
   }
+  const HumanRegs h = humans();
   const double a0 = sh_ract[m.env_ok ? m.el : 0][0], a1 = sh_ract[m.env_ok ? m.el : 0][1];
   double rvx, rvy;
   if (p.robot_kinematics == EBC_HOLONOMIC) {
@@ -910,7 +930,7 @@ __global__ __launch_bounds__(EBC_WAVE) void step_kernel(EbcParams p_in, DevState
   pin_loads(h, pre, rb, gtime);  // every load of the step is back before its first store
   pin(ax);
   pin(ay);
-  int done_flag = service_env(p, s, io, m, h, rb, gtime, lane, env_scratch);
+  int done_flag = service_env(p, s, io, m, [&]() { return h; }, rb, gtime, lane, env_scratch);
   if (m.leader) {
 #pragma unroll
     for (int c = 0; c < 9; ++c) sh_rbn[m.el][c] = rb[c];
@@ -974,12 +994,16 @@ __device__ __forceinline__ void env_role(const EbcParams &p_in, const DevState &
   double rb[9];
   load_robot(s, m, rb);
   double gtime = m.env_ok ? s.time[m.ee] : 0.0;
-  HumanRegs h = load_human(s, m);
-  pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type); pin(gtime);
+  pin(gtime);
 #pragma unroll
   for (int q = 0; q < 9; ++q) pin(rb[q]);
   EBC_MARK(0);
-  const int done = service_env(p, s, io, m, h, rb, gtime, lane, L.env, epoch, block * epb);
+  auto humans = [&]() {
+    HumanRegs h = load_human(read_late(s), m);
+    pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type);
+    return h;
+  };
+  const int done = service_env(p, s, io, m, humans, rb, gtime, lane, L.env, epoch, __builtin_amdgcn_readfirstlane(block * epb));
   if (m.leader) mailbox_put(read_late(s).env_done + m.ee, ((unsigned long long)epoch << 32) | (1u + (unsigned)done));
 }
 
