@@ -228,6 +228,22 @@ def also_kernels(env, batch, dev):
     except Exception as e:  # the headline line must still print
         out.append({"kernel": "lookahead_kernel", "error": repr(e)})
     try:
+        # K steps per call with the robot on ORCA (ebc_step_k): the imitation-learning rollouts of rl/train.py:124-133
+        # — per step the policy's state, the robot's ORCA action and the step, no host work in between
+        K = 50
+        ko = env.alloc_step_k_outputs(K, ("state_rotated", "reward", "done", "info"))
+        roll = lambda: env.step_k_device(ko, K, human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_ORCA,  # noqa: E731
+                                         flags=_abi.FLAG_AUTO_RESET, robot_safety_space=0.15)
+        timed(roll, 1)
+        ms = timed(roll, 4)
+        out.append({"kernel": "ebc_step_k: %d envs x %d steps per call, robot on ORCA (observe + orca_robot_kernel + "
+                              "orca_step_kernel per step), outputs [K][E] left in HBM" % (env.E, K),
+                    "call_ms": ms, "us_per_step": ms * 1e3 / K,
+                    "env_steps_per_s": env.E * K / (ms * 1e-3), "agent_steps_per_s": float(batch.n_humans.sum()) * K / (ms * 1e-3)})
+        del ko
+    except Exception as e:
+        out.append({"kernel": "ebc_step_k", "error": repr(e)})
+    try:
         K0, H, O = env.T, 300, 200  # mlp1 of the reference's shipped eb-cadrl weights (data/eb-cadrl/rl_model_val.pth)
         M = 1024 * 81 * env.R
         g = torch.Generator(device="cpu").manual_seed(0)

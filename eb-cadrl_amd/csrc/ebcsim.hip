@@ -44,6 +44,7 @@ struct Handle {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   bool has_reset = false;
+  double *act_scratch = nullptr;  // ebc_step_k: the ORCA robot's action when the caller keeps none
   bool faulted = false;  // a mailbox wait timed out and was reported: only ebc_reset re-arms the handle
   int orca_gs = 16;  // lanes per human of the ORCA waves
   unsigned epoch = 0;  // fused ORCA steps launched so far (StepGrid::epoch)
@@ -632,27 +633,17 @@ int ebc_set_human_actions(void *handle, int location, const double *act) {
   return EBC_OK;
 }
 
-int ebc_robot_orca(void *handle, double safety_space, int location, double *action) {
-  Handle *h;
-  int rc = check_handle(handle, &h);
-  if (rc) return rc;
-  if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_robot_orca before ebc_reset");
-  if (h->faulted) return fail(EBC_ERR_STATE, "ebc_robot_orca: the handle reported a mailbox fault; ebc_reset re-arms it");
-  if (!action) return fail(EBC_ERR_INVALID, "null action");
-  if (!(safety_space >= 0.0)) return fail(EBC_ERR_INVALID, "safety_space");
-  if (h->p.robot_kinematics != EBC_HOLONOMIC) return fail(EBC_ERR_UNSUPPORTED, "ORCA returns ActionXY: holonomic robots only");
+}  // extern "C"
+
+namespace {
+
+// orca_robot_kernel for every env -> d_act [E][2] (device pointer), on the handle's stream
+int launch_robot_orca(Handle *h, double safety_space, double *d_act) {
   const int others = h->s.N + h->s.S;  // rows of the observation
-  if (others > 32) return fail(EBC_ERR_UNSUPPORTED, "robot ORCA: more than 32 observation rows");
   static const int sizes[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32};
   int gs = 32;
   for (int g : sizes)
     if (g >= others) { gs = g; break; }
-  double *d_act = action;
-  Stager st{h};
-  if (location != EBC_DEVICE) {
-    if ((rc = ensure_stage(h, pad256((size_t)h->s.E * 2 * 8) + 1024)) != EBC_OK) return rc;
-    d_act = st.out(action, (size_t)h->s.E * 2);
-  }
   const int epw = EBC_WAVE / gs;
   const unsigned blocks = (unsigned)((h->s.E + epw - 1) / epw);
 #define RK_(GS) hipLaunchKernelGGL((ebc::orca_robot_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, safety_space, d_act)
@@ -673,7 +664,129 @@ int ebc_robot_orca(void *handle, double safety_space, int location, double *acti
   }
 #undef RK_
   HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+int check_robot_orca(const Handle *h, double safety_space) {
+  if (!(safety_space >= 0.0)) return fail(EBC_ERR_INVALID, "safety_space");
+  if (h->p.robot_kinematics != EBC_HOLONOMIC) return fail(EBC_ERR_UNSUPPORTED, "ORCA returns ActionXY: holonomic robots only");
+  if (h->s.N + h->s.S > 32) return fail(EBC_ERR_UNSUPPORTED, "robot ORCA: more than 32 observation rows");
+  return EBC_OK;
+}
+
+int launch_observe(Handle *h, double *d_ob, float *d_obs) {
+  const size_t rows = (size_t)h->s.E * (h->s.N + h->s.S);
+  const unsigned blocks = (unsigned)((rows + 255) / 256);
+  if (h->T == 17)
+    hipLaunchKernelGGL((ebc::observe_kernel<17>), dim3(blocks), dim3(256), 0, h->stream, h->p, h->s, d_ob, d_obs);
+  else
+    hipLaunchKernelGGL((ebc::observe_kernel<13>), dim3(blocks), dim3(256), 0, h->stream, h->p, h->s, d_ob, d_obs);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ebc_robot_orca(void *handle, double safety_space, int location, double *action) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_robot_orca before ebc_reset");
+  if (h->faulted) return fail(EBC_ERR_STATE, "ebc_robot_orca: the handle reported a mailbox fault; ebc_reset re-arms it");
+  if (!action) return fail(EBC_ERR_INVALID, "null action");
+  if ((rc = check_robot_orca(h, safety_space)) != EBC_OK) return rc;
+  double *d_act = action;
+  Stager st{h};
+  if (location != EBC_DEVICE) {
+    if ((rc = ensure_stage(h, pad256((size_t)h->s.E * 2 * 8) + 1024)) != EBC_OK) return rc;
+    d_act = st.out(action, (size_t)h->s.E * 2);
+  }
+  if ((rc = launch_robot_orca(h, safety_space, d_act)) != EBC_OK) return rc;
   if (location != EBC_DEVICE) return st.finish();
+  return EBC_OK;
+}
+
+int ebc_step_k(void *handle, const EbcStepKArgs *a) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if (!a || a->struct_size != sizeof(EbcStepKArgs)) return fail(EBC_ERR_INVALID, "EbcStepKArgs.struct_size");
+  if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_step_k before ebc_reset");
+  if (h->faulted) return fail(EBC_ERR_STATE, "ebc_step_k: the handle reported a mailbox fault; ebc_reset re-arms it");
+  if (a->K < 1) return fail(EBC_ERR_INVALID, "K");
+  if (a->human_policy != EBC_HUMAN_ORCA && a->human_policy != EBC_HUMAN_LINEAR && a->human_policy != EBC_HUMAN_EXTERNAL)
+    return fail(EBC_ERR_INVALID, "human_policy (a cached look-ahead holds for one step only)");
+  if (a->robot_policy != EBC_ROBOT_EXTERNAL && a->robot_policy != EBC_ROBOT_LINEAR && a->robot_policy != EBC_ROBOT_ORCA)
+    return fail(EBC_ERR_INVALID, "robot_policy");
+  if (a->robot_policy == EBC_ROBOT_EXTERNAL && !a->robot_action) return fail(EBC_ERR_INVALID, "robot_action is NULL");
+  if (a->robot_policy == EBC_ROBOT_LINEAR && h->p.robot_kinematics != EBC_HOLONOMIC)
+    return fail(EBC_ERR_UNSUPPORTED, "the linear robot policy is holonomic (simulator/policy/linear.py:11)");
+  if (a->robot_policy == EBC_ROBOT_ORCA && (rc = check_robot_orca(h, a->robot_safety_space)) != EBC_OK) return rc;
+  if (a->flags & EBC_FLAG_BORDER) return fail(EBC_ERR_UNSUPPORTED, "ebc_step_k: no border");
+  const DevState &s = h->s;
+  const size_t E = s.E, R = s.N + s.S, T = h->T, K = (size_t)a->K;
+  const double *d_act_in = a->robot_action;
+  float *d_state = a->state_rotated, *d_obs = a->obs_rotated;
+  long long *d_rows = a->n_rows;
+  double *d_act_out = a->robot_action_out, *d_reward = a->reward, *d_dmin = a->dmin, *d_goal = a->dist_to_goal;
+  uint8_t *d_done = a->done, *d_info = a->info;
+  Stager st{h};
+  if (a->location != EBC_DEVICE) {
+    const size_t need = K * (pad256(E * 2 * 8) * 2 + pad256(E * 8) * 3 + pad256(E) * 2 + pad256(E * 3 * 8) +
+                             pad256(E * R * T * 4) * 2) + pad256(E * 2 * 8) + 8192;
+    if ((rc = ensure_stage(h, need)) != EBC_OK) return rc;
+    if ((rc = st.in(a->robot_policy == EBC_ROBOT_EXTERNAL ? a->robot_action : nullptr, K * E * 2, &d_act_in)) != EBC_OK) return rc;
+    d_state = st.out(a->state_rotated, K * E * R * T); d_rows = st.out(a->n_rows, K * E);
+    d_act_out = st.out(a->robot_action_out, K * E * 2); d_reward = st.out(a->reward, K * E);
+    d_done = st.out(a->done, K * E); d_info = st.out(a->info, K * E); d_dmin = st.out(a->dmin, K * E * 3);
+    d_goal = st.out(a->dist_to_goal, K * E); d_obs = st.out(a->obs_rotated, K * E * R * T);
+  }
+  // the ORCA robot's action of step k needs a home when the caller does not ask for the actions
+  double *orca_act = nullptr;
+  if (a->robot_policy == EBC_ROBOT_ORCA && !d_act_out) {
+    if (a->location != EBC_DEVICE) {
+      orca_act = (double *)((char *)h->stage + st.off);
+      st.off += pad256(E * 2 * 8);
+    } else {
+      if (!h->act_scratch) {
+        void *ptr = nullptr;
+        HIP_TRY(hipMalloc(&ptr, E * 2 * 8));
+        h->allocs.push_back(ptr);
+        h->act_scratch = (double *)ptr;
+      }
+      orca_act = h->act_scratch;
+    }
+  }
+  for (size_t k = 0; k < K; ++k) {
+    if (d_state && (rc = launch_observe(h, nullptr, d_state + k * E * R * T)) != EBC_OK) return rc;
+    if (d_rows) {
+      hipLaunchKernelGGL(ebc::row_counts_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, h->stream, h->s, d_rows + k * E);
+      HIP_TRY(hipGetLastError());
+    }
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    io.auto_reset = (a->flags & EBC_FLAG_AUTO_RESET) ? 1 : 0;
+    io.robot_policy = a->robot_policy == EBC_ROBOT_LINEAR ? EBC_ROBOT_LINEAR : EBC_ROBOT_EXTERNAL;
+    if (a->robot_policy == EBC_ROBOT_ORCA) {
+      double *act = d_act_out ? d_act_out + k * E * 2 : orca_act;
+      if ((rc = launch_robot_orca(h, a->robot_safety_space, act)) != EBC_OK) return rc;
+      io.robot_action = act;
+    } else if (a->robot_policy == EBC_ROBOT_EXTERNAL) {
+      io.robot_action = d_act_in + k * E * 2;
+    }
+    io.reward = d_reward ? d_reward + k * E : nullptr;
+    io.done = d_done ? d_done + k * E : nullptr;
+    io.info = d_info ? d_info + k * E : nullptr;
+    io.dmin = d_dmin ? d_dmin + k * E * 3 : nullptr;
+    io.dist_to_goal = d_goal ? d_goal + k * E : nullptr;
+    // with EBC_ROBOT_ORCA the step reads the action from where robot ORCA left it (already robot_action_out[k])
+    io.robot_action_out = (a->robot_policy != EBC_ROBOT_ORCA && d_act_out) ? d_act_out + k * E * 2 : nullptr;
+    io.obs_rotated = d_obs ? d_obs + k * E * R * T : nullptr;
+    if ((rc = launch_step(h, io, a->human_policy)) != EBC_OK) return rc;
+  }
+  if (a->location != EBC_DEVICE) return st.finish();
   return EBC_OK;
 }
 
@@ -755,12 +868,7 @@ int ebc_observe(void *handle, int location, double *ob, float *obs_rotated) {
     d_ob = st.out(ob, rows * 5);
     d_obs = st.out(obs_rotated, rows * T);
   }
-  const unsigned blocks = (unsigned)((rows + 255) / 256);
-  if (h->T == 17)
-    hipLaunchKernelGGL((ebc::observe_kernel<17>), dim3(blocks), dim3(256), 0, h->stream, h->p, h->s, d_ob, d_obs);
-  else
-    hipLaunchKernelGGL((ebc::observe_kernel<13>), dim3(blocks), dim3(256), 0, h->stream, h->p, h->s, d_ob, d_obs);
-  HIP_TRY(hipGetLastError());
+  if ((rc = launch_observe(h, d_ob, d_obs)) != EBC_OK) return rc;
   if (location != EBC_DEVICE) return st.finish();
   return EBC_OK;
 }

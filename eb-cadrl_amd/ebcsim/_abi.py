@@ -14,7 +14,7 @@ ADULT, BICYCLE, CHILD, ADULT_STATIC, ROBOT = 0, 1, 2, 3, 4
 HOLONOMIC, UNICYCLE = 0, 1
 HOST, DEVICE = 0, 1
 HUMAN_EXTERNAL, HUMAN_LINEAR, HUMAN_ORCA, HUMAN_CACHED = 0, 1, 2, 3
-ROBOT_EXTERNAL, ROBOT_LINEAR = 0, 1
+ROBOT_EXTERNAL, ROBOT_LINEAR, ROBOT_ORCA = 0, 1, 2
 FLAG_AUTO_RESET, FLAG_BORDER = 1, 2
 
 _pd = C.c_void_p  # every buffer pointer travels as an address
@@ -80,6 +80,21 @@ class EbcLookaheadArgs(C.Structure):
     ] + [
         (k, _pd) for k in ("actions", "border", "reward", "done", "info", "dmin", "next_ob",
                            "rows_rotated")
+    ]
+
+
+class EbcStepKArgs(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("location", C.c_int32),
+        ("K", C.c_int32),
+        ("human_policy", C.c_int32),
+        ("robot_policy", C.c_int32),
+        ("flags", C.c_int32),
+        ("robot_safety_space", C.c_double),
+    ] + [
+        (k, _pd) for k in ("robot_action", "state_rotated", "n_rows", "robot_action_out", "reward", "done", "info",
+                           "dmin", "dist_to_goal", "obs_rotated")
     ]
 
 

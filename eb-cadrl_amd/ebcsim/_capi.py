@@ -27,6 +27,7 @@ SYMBOLS = {
     "ebc_robot_orca": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
     "ebc_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_lookahead": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ebc_step_k": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_row_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ebc_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

@@ -258,6 +258,56 @@ class BatchedEnv:
         if rc:
             _capi.check(rc)
 
+    _STEP_K_SHAPES = staticmethod(lambda E, R, T: dict(
+        state_rotated=((E, R, T), "float32"), n_rows=((E,), "int64"), robot_action_out=((E, 2), "float64"),
+        reward=((E,), "float64"), done=((E,), "uint8"), info=((E,), "uint8"), dmin=((E, 3), "float64"),
+        dist_to_goal=((E,), "float64"), obs_rotated=((E, R, T), "float32")))
+
+    def _step_k_args(self, K, location, ptr, human_policy, robot_policy, flags, robot_safety_space, robot_action_ptr):
+        args = _abi.EbcStepKArgs()
+        args.struct_size = C.sizeof(args)
+        args.location, args.K = location, int(K)
+        args.human_policy, args.robot_policy, args.flags = int(human_policy), int(robot_policy), int(flags)
+        args.robot_safety_space = float(robot_safety_space)
+        args.robot_action = robot_action_ptr
+        for k, v in ptr.items():
+            setattr(args, k, v)
+        return args
+
+    def step_k(self, K, keys=("reward", "done", "info", "state_rotated"), robot_action=None,
+               human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=0, robot_safety_space=0.0):
+        """K steps in one call (ebc_step_k), host buffers: returns {key: array [K, ...]}."""
+        shapes = self._STEP_K_SHAPES(self.E, self.R, self.T)
+        out = {k: np.zeros((K,) + shapes[k][0], dtype=shapes[k][1]) for k in keys}
+        ra = None
+        if robot_action is not None:
+            ra = np.ascontiguousarray(robot_action, dtype=np.float64).reshape(K, self.E, 2)
+        args = self._step_k_args(K, _abi.HOST, {k: v.ctypes.data for k, v in out.items()}, human_policy, robot_policy,
+                                 flags, robot_safety_space, None if ra is None else ra.ctypes.data)
+        _capi.check(self._L.ebc_step_k(self._h, C.addressof(args)))
+        return out
+
+    def alloc_step_k_outputs(self, K, keys=("reward", "done", "info", "state_rotated")):
+        """torch CUDA tensors [K, ...] for step_k_device(); the caller owns them."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        shapes = self._STEP_K_SHAPES(self.E, self.R, self.T)
+        return {k: torch.zeros((K,) + shapes[k][0], dtype=getattr(torch, shapes[k][1]), device=dev) for k in keys}
+
+    def step_k_device(self, outputs, K, robot_action=None, human_policy=_abi.HUMAN_ORCA,
+                      robot_policy=_abi.ROBOT_LINEAR, flags=0, robot_safety_space=0.0):
+        """Enqueue K steps (ebc_step_k) writing into torch CUDA tensors [K, ...] (not copied)."""
+        for k, t in outputs.items():
+            if t.shape[0] != K or not t.is_contiguous():
+                raise ValueError("%s must be a contiguous [K, ...] tensor" % k)
+        if robot_action is not None and (robot_action.dtype.itemsize != 8 or robot_action.numel() != K * self.E * 2
+                                         or not robot_action.is_contiguous()):
+            raise ValueError("robot_action must be a contiguous float64 [K, E, 2] tensor")
+        args = self._step_k_args(K, _abi.DEVICE, {k: t.data_ptr() for k, t in outputs.items()}, human_policy,
+                                 robot_policy, flags, robot_safety_space,
+                                 None if robot_action is None else robot_action.data_ptr())
+        _capi.check(self._L.ebc_step_k(self._h, C.addressof(args)))
+
     def alloc_lookahead_outputs(self, n_actions, keys=("reward", "done", "info", "rows_rotated")):
         """torch CUDA tensors for lookahead_device(); the caller owns them."""
         import torch

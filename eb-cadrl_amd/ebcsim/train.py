@@ -358,27 +358,19 @@ def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HU
     ebc_step, auto-reset) for `steps` steps; the states of every episode that ended inside the window in
     ReachGoal or a collision (explorer.py:82-92) go to `memory` with their discounted returns.  Returns
     (steps stored, episodes ended)."""
-    dev = memory.states.device
     E, R, T = env.E, env.R, env.T
-    states = torch.zeros((steps, E, R, T), dtype=torch.float32, device=dev)
-    rewards = torch.zeros((steps, E), dtype=torch.float64, device=dev)
-    dones = torch.zeros((steps, E), dtype=torch.uint8, device=dev)
-    act = torch.zeros((E, 2), dtype=torch.float64, device=dev)
-    infos = torch.zeros((steps, E), dtype=torch.uint8, device=dev)
-    outs = env.alloc_step_outputs(("reward", "done", "info"))
     v_pref = float(env.get_state()["robot"][0, 7])
     gamma_bar = gamma ** (env.params.time_step * v_pref)
     ragged = bool(getattr(env, "ragged", False))
-    rows = torch.full((steps, E), R, dtype=torch.int64, device=dev) if ragged else None
-    for t in range(steps):
-        env.observe_device(states[t])        # policy.last_state, transformed (explorer.py:43, :162)
-        if ragged:
-            env.row_counts_device(rows[t])
-        env.robot_orca_device(act, safety_space)
-        env.step_device(outs, robot_action=act, human_policy=human_policy, flags=_abi.FLAG_AUTO_RESET)
-        rewards[t].copy_(outs["reward"])
-        dones[t].copy_(outs["done"])
-        infos[t].copy_(outs["info"])
+    # the whole window in ONE call through the C ABI (ebc_step_k): per step the library enqueues the state the
+    # policy sees (policy.last_state transformed, explorer.py:43, :162), the robot's ORCA action and the step,
+    # every output written at its step index; no host work between the steps
+    keys = ("state_rotated", "reward", "done", "info") + (("n_rows",) if ragged else ())
+    outs = env.alloc_step_k_outputs(steps, keys)
+    env.step_k_device(outs, steps, human_policy=human_policy, robot_policy=_abi.ROBOT_ORCA,
+                      flags=_abi.FLAG_AUTO_RESET, robot_safety_space=safety_space)
+    states, rewards, dones, infos = outs["state_rotated"], outs["reward"], outs["done"], outs["info"]
+    rows = outs["n_rows"] if ragged else None
     values, keep = il_value_targets(rewards, dones, gamma_bar, infos)
     keep = keep.reshape(-1)
     memory.push(states.reshape(steps * E, R, T)[keep], values.reshape(-1)[keep],

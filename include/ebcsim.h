@@ -81,7 +81,8 @@ enum {
 
 enum {
   EBC_ROBOT_EXTERNAL = 0, /* robot_action[E][2] supplied */
-  EBC_ROBOT_LINEAR = 1    /* simulator/policy/linear.py:17-23 applied to the robot, on device */
+  EBC_ROBOT_LINEAR = 1,   /* simulator/policy/linear.py:17-23 applied to the robot, on device */
+  EBC_ROBOT_ORCA = 2      /* ebc_step_k only: the robot on ORCA (ebc_robot_orca), the imitation-learning demonstrator */
 };
 
 /* flags */
@@ -251,6 +252,37 @@ int ebc_robot_orca(void *handle, double safety_space, int location, double *acti
  * steps (EBC_ERR_STATE) until ebc_reset has re-armed it. */
 int ebc_step(void *handle, const EbcStepArgs *args);
 int ebc_lookahead(void *handle, const EbcLookaheadArgs *args);
+
+/* K consecutive env.step calls for every env with a robot policy that lives on the device, in ONE call: the
+ * episode loop of Explorer.run_one_episode (rl/utils/explorer.py:33-45: act -> step -> keep state, action,
+ * reward) without a host round trip per step — with EBC_ROBOT_ORCA the imitation-learning rollouts of
+ * rl/train.py:124-133.  Per step k the library enqueues: the rotated joint state the policy sees
+ * (MultiHumanRL.transform, rl/policy/multi_human_rl.py:128-149 -> state_rotated[k]), the robot's action
+ * (EBC_ROBOT_ORCA: ebc_robot_orca with robot_safety_space; EBC_ROBOT_LINEAR; EBC_ROBOT_EXTERNAL:
+ * robot_action[k]), and ebc_step with every output written at index k.  Same arithmetic, launch for launch,
+ * as K calls of ebc_observe / ebc_robot_orca / ebc_step (tests hold it equal to K oracle steps); what it
+ * removes is the per-step host work.  EBC_FLAG_AUTO_RESET keeps every env in an episode. */
+typedef struct EbcStepKArgs {
+  uint32_t struct_size;
+  int32_t location;      /* of every pointer below */
+  int32_t K;             /* steps, >= 1 */
+  int32_t human_policy;  /* EBC_HUMAN_ORCA, _LINEAR or _EXTERNAL (the same supplied velocities every step) */
+  int32_t robot_policy;  /* EBC_ROBOT_ORCA, _LINEAR or _EXTERNAL */
+  int32_t flags;
+  double robot_safety_space;  /* EBC_ROBOT_ORCA: the policy's safety_space (rl/train.py:127-129) */
+  const double *robot_action; /* [K][E][2], EBC_ROBOT_EXTERNAL only */
+  /* outputs, each may be NULL */
+  float *state_rotated;     /* [K][E][R][T] rotated joint state BEFORE step k (policy.last_state, explorer.py:43) */
+  long long *n_rows;        /* [K][E] observation rows that exist before step k (ebc_row_counts) */
+  double *robot_action_out; /* [K][E][2] the action taken at step k */
+  double *reward;           /* [K][E] */
+  uint8_t *done;            /* [K][E] */
+  uint8_t *info;            /* [K][E] */
+  double *dmin;             /* [K][E][3] */
+  double *dist_to_goal;     /* [K][E] */
+  float *obs_rotated;       /* [K][E][R][T] rotated observation returned by step k */
+} EbcStepKArgs;
+int ebc_step_k(void *handle, const EbcStepKArgs *args);
 int ebc_get_state(void *handle, const EbcStateView *view);
 
 /* Rows of the observation that exist, per env: len(ob) of the list env.step returns (humans, then the

@@ -338,6 +338,28 @@ class OracleEnv:
             raise RuntimeError("orc_robot_orca failed: %d" % rc)
         return act
 
+    def step_k(self, K, keys=("reward", "done", "info", "state_rotated"), robot_action=None,
+               human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=0, robot_safety_space=0.0):
+        """The checker's ebc_step_k: K times [observe -> robot action -> step], outputs stacked [K, ...]."""
+        out = {k: [] for k in keys}
+        for k in range(K):
+            if "state_rotated" in out:
+                out["state_rotated"].append(self.observe()[1])
+            if "n_rows" in out:
+                out["n_rows"].append(self.row_counts())
+            if robot_policy == _abi.ROBOT_ORCA:
+                act = self.robot_orca(robot_safety_space)
+                o = self.step(robot_action=act, human_policy=human_policy, flags=flags)
+                o["robot_action_out"] = act
+            elif robot_policy == _abi.ROBOT_EXTERNAL:
+                o = self.step(robot_action=np.asarray(robot_action)[k], human_policy=human_policy, flags=flags)
+            else:
+                o = self.step(human_policy=human_policy, robot_policy=_abi.ROBOT_LINEAR, flags=flags)
+            for key in keys:
+                if key not in ("state_rotated", "n_rows"):
+                    out[key].append(o[key])
+        return {k: np.stack(v) for k, v in out.items()}
+
     def row_counts(self):
         """Observation rows that exist per env (the checker's ebc_row_counts)."""
         return self.a["n_humans"].astype(np.int64) + (self.a["n_static"].astype(np.int64) if self.S else 0)

@@ -186,6 +186,24 @@ class CpuDeviceEnv(object):
         import torch
         n_rows.copy_(torch.from_numpy(self._o.row_counts()))
 
+    def alloc_step_k_outputs(self, K, keys=("reward", "done", "info", "state_rotated")):
+        import torch
+        E, R, T = self.E, self.R, self.T
+        shapes = dict(state_rotated=((E, R, T), torch.float32), n_rows=((E,), torch.int64),
+                      robot_action_out=((E, 2), torch.float64), reward=((E,), torch.float64), done=((E,), torch.uint8),
+                      info=((E,), torch.uint8), dmin=((E, 3), torch.float64), dist_to_goal=((E,), torch.float64),
+                      obs_rotated=((E, R, T), torch.float32))
+        return {k: torch.zeros((K,) + shapes[k][0], dtype=shapes[k][1]) for k in keys}
+
+    def step_k_device(self, outputs, K, robot_action=None, human_policy=_abi.HUMAN_ORCA,
+                      robot_policy=_abi.ROBOT_LINEAR, flags=0, robot_safety_space=0.0):
+        import torch
+        out = self._o.step_k(K, tuple(outputs), None if robot_action is None else robot_action.numpy(), human_policy,
+                             robot_policy, flags, robot_safety_space)
+        for k, t in outputs.items():
+            t.copy_(torch.from_numpy(out[k]))
+        self.steps += K
+
     def robot_orca_device(self, actions, safety_space=0.0):
         import torch
         actions.copy_(torch.from_numpy(self._o.robot_orca(safety_space)))

@@ -335,6 +335,62 @@ def test_baseline_sizes_vs_oracle(workload, E, humans, steps):
         np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
 
 
+@pytest.mark.parametrize("robot", ["orca", "linear", "external"])
+def test_step_k_equals_k_oracle_steps(robot):
+    """ebc_step_k: K steps in one call (rl/utils/explorer.py:33-45 without a host round trip per step) against
+    K oracle steps — the state the policy sees, the robot's action, reward / done / info and the returned
+    observation of every step, through restarts (auto-reset, short time limit)."""
+    from oracle import oracle
+    z = load("traj_n10_walls_t17_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    params.time_limit = 4
+    E, K = 70, 45
+    b, _ = _random_batch(_config_text(meta), [31000 + e for e in range(E)])
+    g = _env(params, E, b.N, b.S)
+    o = oracle.OracleEnv(params, E, b.N, b.S)
+    g.reset(b)
+    o.reset(b)
+    keys = ("state_rotated", "n_rows", "robot_action_out", "reward", "done", "info", "dmin", "dist_to_goal", "obs_rotated")
+    kw = dict(flags=_abi.FLAG_AUTO_RESET, human_policy=_abi.HUMAN_ORCA)
+    if robot == "orca":
+        kw.update(robot_policy=_abi.ROBOT_ORCA, robot_safety_space=0.15)
+    elif robot == "linear":
+        kw.update(robot_policy=_abi.ROBOT_LINEAR)
+    else:
+        rs = np.random.RandomState(5)
+        space = ebc_actions.build_action_space(float(b.robot[0, 7]))
+        kw.update(robot_policy=_abi.ROBOT_EXTERNAL, robot_action=space[rs.randint(len(space), size=(K, E))])
+        keys = tuple(k for k in keys if k != "robot_action_out")
+    og = g.step_k(K, keys, **kw)
+    oo = o.step_k(K, keys, **kw)
+    for k in ("done", "info", "n_rows"):
+        np.testing.assert_array_equal(og[k], oo[k], err_msg=k)
+    for k in ("reward", "dmin", "dist_to_goal", "robot_action_out"):
+        if k in og:
+            both_inf = np.isinf(og[k]) & np.isinf(oo[k])
+            np.testing.assert_allclose(np.where(both_inf, 0, og[k]), np.where(both_inf, 0, oo[k]), atol=1e-9, rtol=0, err_msg=k)
+    for k in ("state_rotated", "obs_rotated"):
+        np.testing.assert_allclose(og[k], oo[k], atol=1e-5, rtol=1e-5, err_msg=k)
+    assert int(oo["done"].sum()) > E  # restarts happened inside the window
+    sg, so = g.get_state(), o.get_state()
+    for k in sg:
+        np.testing.assert_allclose(sg[k], so[k], atol=1e-9, rtol=0, err_msg=k)
+    # the device form writes the same into caller-owned tensors
+    import torch
+    g.reset(b)
+    g.use_torch_stream()
+    outs = g.alloc_step_k_outputs(K, ("reward", "done", "state_rotated"))
+    kw2 = dict(kw)
+    if "robot_action" in kw2:
+        kw2["robot_action"] = torch.tensor(kw2["robot_action"], dtype=torch.float64, device="cuda:0")
+    g.step_k_device(outs, K, **kw2)
+    g.synchronize()
+    np.testing.assert_array_equal(outs["done"].cpu().numpy(), oo["done"])
+    np.testing.assert_allclose(outs["reward"].cpu().numpy(), oo["reward"], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(outs["state_rotated"].cpu().numpy(), oo["state_rotated"], atol=1e-5, rtol=1e-5)
+
+
 def test_mailbox_fault_is_reported_once_and_reset_rearms():
     """The give-up path of the one-launch step (ebc_kernels.h mailbox_wait / EBC_SPIN_LIMIT), never taken in a
     healthy run, exercised ONCE with the test build: a withheld hand-off ends in EBC_ERR_DEVICE instead of a
