@@ -187,6 +187,15 @@ REFERENCE_PYTHON = {
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
+def ebc_scene_slice(batch, n):
+    """The first n scenes of a SceneBatch."""
+    from ebcsim import scene as ebc_scene
+    return ebc_scene.SceneBatch(n, batch.N, batch.S, *[
+        None if getattr(batch, k) is None else getattr(batch, k)[:n] for k in (
+            "n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
+            "n_static", "spx", "spy", "sradius", "grid", "robot")])
+
+
 def also_kernels(env, batch, dev):
     """The two other kernels of the path with a roofline of their own, measured live (HIP events on
     the launch stream; inputs resident in HBM): the 81-action look-ahead sweep whose rotated rows
@@ -243,6 +252,42 @@ def also_kernels(env, batch, dev):
         del ko
     except Exception as e:
         out.append({"kernel": "ebc_step_k", "error": repr(e)})
+    try:
+        # One robot decision per env for 1024 envs: 81-action look-ahead sweep + the SARL value network (the
+        # architecture of the reference's shipped eb-cadrl weights, data/eb-cadrl/policy_x2_agent_type.config;
+        # random-init weights) on 1024 x 81 pairs x R rows + top-2 refinement + argmax
+        # (rl/policy/multi_human_rl.py:38-80, rl/policy/sarl.py:38-82)
+        from ebcsim.batched import BatchedEnv
+        from ebcsim.sarl import DeviceSarlPolicy, SarlValueNet
+        from ebcsim.train import SarlModule
+        Ed = min(1024, env.E)
+        sub = ebc_scene_slice(batch, Ed)
+        denv = BatchedEnv(env.params, Ed, batch.N, batch.S, device=dev.index or 0)
+        denv.reset(sub)
+        denv.use_torch_stream()
+        torch.manual_seed(0)
+        mod = SarlModule(env.T, [300, 200], [200, 100], [300, 200, 200, 1], [200, 200, 1])
+        net = SarlValueNet({k: v.detach() for k, v in mod.state_dict().items()}, device=str(dev))
+        space = ebc_actions.build_action_space(float(batch.robot[0, 7]))
+        pol = DeviceSarlPolicy(net, space, 0.9)
+        dec = lambda: pol.decide(denv)  # noqa: E731
+        timed(dec, 2)
+        ms = timed(dec, 5)
+        A, R = len(space), denv.R
+        row_macs = env.T * 300 + 300 * 200 + 200 * 200 + 200 * 100 + 200 * 200 + 200 * 200 + 200
+        pair_macs = 200 * 200 + (6 + 100) * 300 + 300 * 200 + 200 * 200 + 200
+        macs = float(Ed) * A * (R * row_macs + pair_macs)
+        tf = 3.0 * 2.0 * macs / (ms * 1e-3) / 1e12  # three bf16 MFMA products per float32 product
+        out.append({"kernel": "decision: %d envs x %d actions x %d rows, look-ahead sweep + SARL x2 network (split-bf16 MFMA "
+                              "blocks, pair kernels, float32 tail) + top-2 float32 refinement + argmax" % (Ed, A, R),
+                    "ms_per_decision_batch": ms, "decisions_per_s": Ed / (ms * 1e-3),
+                    "native_blocks": bool(net._native_blocks()),
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tf / MFMA_BF16_PEAK_TFLOPS, "f32_equivalent_tflops": tf / 3.0,
+                                 "algorithmic_macs_per_batch": macs}})
+        del pol, net, denv
+    except Exception as e:
+        out.append({"kernel": "decision", "error": repr(e)})
     try:
         K0, H, O = env.T, 300, 200  # mlp1 of the reference's shipped eb-cadrl weights (data/eb-cadrl/rl_model_val.pth)
         M = 1024 * 81 * env.R

@@ -1317,6 +1317,25 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
 #ifndef EBC_ROLE_MASK  // register-budget experiments: compile a subset of the roles
 #define EBC_ROLE_MASK 15
 #endif
+#ifdef EBC_ORCA_FIRST
+  // Experiment (measured slower: 18.4 against 17.4 us per step, profiles/r02_block_order_ab.txt).  ENV + ORCA waves
+  // (683 + 5852 at 4096 x 10) are more than the chip keeps resident (6144 at six waves per SIMD): whichever
+  // role comes second has waves that start only when slots free up (~3.5-6 us).  With ENV first the late
+  // starters are ORCA waves and the launch ends with them; with ORCA first they are ENV waves — and their
+  // chain (9 us) then ends later than the late ORCA waves did.
+  if (b < orca_blocks) {
+    const OrcaHot hot{hot_E, hot_N, hot_magic, hot_shift, hot_tile, hot_n_humans};
+    if (EBC_ROLE_MASK & 2) orca_role<GS>(p_in, s_in, hot, hot_vel, hot_epoch, lds, b, lane);
+    return;
+  }
+  b -= orca_blocks;
+  if (b < env_blocks) {
+    __builtin_amdgcn_s_setprio(3);  // the long dependent chain of the launch
+    if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, g.epoch, lane);
+    return;
+  }
+  b -= env_blocks;
+#else
   if (b < env_blocks) {
     __builtin_amdgcn_s_setprio(3);  // the long dependent chain of the launch
     if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, g.epoch, lane);
@@ -1329,6 +1348,7 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
     return;
   }
   b -= orca_blocks;
+#endif
   if (b < g.rows_blocks) {
     if (EBC_ROLE_MASK & 4) rows_role<T>(p_in, s_in, io_in, L, b, g.rows_epw, g.epoch, lane);
     return;

@@ -26,4 +26,6 @@ if [ -f eb-cadrl_amd/lib/libebcsim_trace.so ]; then
   EBCSIM_LIB=$root/eb-cadrl_amd/lib/libebcsim_trace.so python3 tools/wave_timeline.py metric > $out/wave_timeline.txt 2>&1
 fi
 [ -x tools/bin/launch_rate ] && tools/bin/launch_rate > $out/launch_rate.txt 2>&1
+# the robot decision (look-ahead sweep + value network): per-kernel times
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/sarl -o sarl -- python3 $root/tools/sarl_profile.py 1024 > $out/sarl.log 2>&1) || true
 ls $out
