@@ -22,6 +22,9 @@
 namespace ebc {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float vn_f32x4 __attribute__((ext_vector_type(4)));
+typedef vn_f32x4 __attribute__((address_space(3))) *LdsF4;  // explicit LDS pointers: no flat-address casts in the loops
+#define EBC_VN_XROW 144  // bytes per row of a wave's input transposition tile: 128 + 16 (conflict-free 16-byte reads)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Frag2 {  // one operand fragment, split
@@ -123,18 +126,52 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
   stage(0, 0);
   // the input tile as B fragments, natural k order: element j of k-step s is k = 16 s + 8 half + j
   Frag2 x[TI][2][1];
+  if (TI >= 2 && (K0 & 3) == 0) {
+    // Wide inputs (the 200-float h1 rows of mlp2 / attention) through LDS.  A lane needs ITS row, 8 consecutive
+    // floats per k-step: read straight from memory that is 28 16-byte loads per lane at a row stride, every
+    // 128-byte line touched by eight different wave instructions with 200+ KB per CU in flight — the lines
+    // do not survive in the 32 KB L1 and come from L2 eight times (measured: the input phase cost 0.25-0.3 ms of
+    // the 0.49 / 0.68 ms launches on 0.5 M rows).  Instead, per 32-float column block: 8 consecutive lanes read
+    // one row's 128 bytes (each line exactly once), the wave parks the block in its own LDS tile (row pitch
+    // 144 B: the 16-byte reads of 16 lanes then fall in 16 different bank groups) and reads it back row per lane.
+    unsigned char *xt_generic = reinterpret_cast<unsigned char *>(wbuf) + 2 * (size_t)PER_U * 16 + (size_t)hidden_tiles * 32 * 4;
+    const LdsF4 xt = (LdsF4)(xt_generic + (size_t)wave * 32 * EBC_VN_XROW);
+    const int m0 = (blockIdx.x * NW + wave) * 32;
+    const int piece = lane & 7, rsub = lane >> 3;
 #pragma unroll
-  for (int u = 0; u < TI; ++u)
+    for (int i = 0; i < TI; ++i) {
+      vn_f32x4 v4[4];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int kk = u * 32 + 16 * s + 8 * half + j;
-        v[j] = (m < M && kk < K0) ? X[(size_t)m * K0 + kk] : 0.0f;
+      for (int q = 0; q < 4; ++q) {
+        const int r = rsub + 8 * q, kk = i * 32 + 4 * piece;
+        v4[q] = vn_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (m0 + r < M && kk + 3 < K0) v4[q] = *reinterpret_cast<const vn_f32x4 *>(X + (size_t)(m0 + r) * K0 + kk);
       }
-      x[u][s][0] = split8(v);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xt[((rsub + 8 * q) * EBC_VN_XROW + piece * 16) / 16] = v4[q];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const vn_f32x4 a = xt[(col * EBC_VN_XROW + s2 * 64 + half * 32) / 16], b = xt[(col * EBC_VN_XROW + s2 * 64 + half * 32 + 16) / 16];
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        x[i][s2][0] = split8(v);
+      }
+      __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the next column block
     }
+  } else {
+#pragma unroll
+    for (int u = 0; u < TI; ++u)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int kk = u * 32 + 16 * s + 8 * half + j;
+          v[j] = (m < M && kk < K0) ? X[(size_t)m * K0 + kk] : 0.0f;
+        }
+        x[u][s][0] = split8(v);
+      }
+  }
   f32x16 out[TO][1];
 #pragma unroll
   for (int t = 0; t < TO; ++t) out[t][0] = bias_tile(L2, t, lane);
