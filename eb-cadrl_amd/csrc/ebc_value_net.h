@@ -25,6 +25,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float vn_f32x4 __attribute__((ext_vector_type(4)));
 typedef vn_f32x4 __attribute__((address_space(3))) *LdsF4;  // explicit LDS pointers: no flat-address casts in the loops
 #define EBC_VN_XROW 144  // bytes per row of a wave's input transposition tile: 128 + 16 (conflict-free 16-byte reads)
+#define EBC_VN_GROUPS 4         // group-term rows a wave parks in LDS (its 32 rows span at most that many groups)
+#define EBC_VN_GROUP_PITCH 912  // bytes per parked row: 224 floats + 16
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Frag2 {  // one operand fragment, split
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
   stage(0, 0);
   // the input tile as B fragments, natural k order: element j of k-step s is k = 16 s + 8 half + j
   Frag2 x[TI][2][1];
-  if (TI >= 2 && (K0 & 3) == 0) {
+  if (TI >= 2 && (K0 & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)PER_U * 16) {
     // Wide inputs (the 200-float h1 rows of mlp2 / attention) through LDS.  A lane needs ITS row, 8 consecutive
     // floats per k-step: read straight from memory that is 28 16-byte loads per lane at a row stride, every
     // 128-byte line touched by eight different wave instructions with 200+ KB per CU in flight — the lines
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
     // the 0.49 / 0.68 ms launches on 0.5 M rows).  Instead, per 32-float column block: 8 consecutive lanes read
     // one row's 128 bytes (each line exactly once), the wave parks the block in its own LDS tile (row pitch
     // 144 B: the 16-byte reads of 16 lanes then fall in 16 different bank groups) and reads it back row per lane.
-    unsigned char *xt_generic = reinterpret_cast<unsigned char *>(wbuf) + 2 * (size_t)PER_U * 16 + (size_t)hidden_tiles * 32 * 4;
-    const LdsF4 xt = (LdsF4)(xt_generic + (size_t)wave * 32 * EBC_VN_XROW);
+    // the tiles live in weight buffer 1: nothing is staged into it before the barrier in front of the loop
+    const LdsF4 xt = (LdsF4)(reinterpret_cast<unsigned char *>(wbuf + PER_U) + (size_t)wave * 32 * EBC_VN_XROW);
     const int m0 = (blockIdx.x * NW + wave) * 32;
     const int piece = lane & 7, rsub = lane >> 3;
 #pragma unroll
@@ -177,11 +179,37 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
   for (int t = 0; t < TO; ++t) out[t][0] = bias_tile(L2, t, lane);
   // the group term of hidden tile u for this lane's row: units 8 g + 4 half + 0..3 of the tile for g = 0..3
   const float *gb = (GROUP && m < M) ? ex.row_bias + (size_t)(m / ex.group_rows) * ex.H : nullptr;
+  // The group terms of the (at most EBC_VN_GROUPS) groups a wave's 32 rows belong to wait in LDS: read from memory
+  // inside the loop (four 16-byte loads per lane and hidden tile) their waits also waited for the weight staging
+  // issued behind them (one in-order counter), and the loop ran at 0.42 instead of ~0.25 ms per 0.5 M rows.
+  const int m0w = (blockIdx.x * NW + wave) * 32;
+  const bool g_lds = GROUP && (ex.H & 3) == 0 && ex.group_rows > 0 && (31 / ex.group_rows + 2) <= EBC_VN_GROUPS;
+  const int Hp = (ex.H + 3) & ~3;  // floats per parked row
+  const LdsF4 gt = (LdsF4)(reinterpret_cast<unsigned char *>(wbuf) + 2 * (size_t)PER_U * 16 + (size_t)hidden_tiles * 32 * 4 +
+                           (size_t)wave * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH);
+  if (g_lds) {
+    const int first = m0w / ex.group_rows;
+    const int groups_total = (M + ex.group_rows - 1) / ex.group_rows;
+    for (int q = lane; q < EBC_VN_GROUPS * (Hp / 4); q += 64) {
+      const int gq = q / (Hp / 4), c4 = q - gq * (Hp / 4);
+      vn_f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (first + gq < groups_total) v = *reinterpret_cast<const vn_f32x4 *>(ex.row_bias + (size_t)(first + gq) * ex.H + 4 * c4);
+      gt[(gq * EBC_VN_GROUP_PITCH) / 16 + c4] = v;
+    }
+  }
+  const int g_local = (GROUP && m < M) ? m / ex.group_rows - m0w / ex.group_rows : 0;
   auto group_bias = [&](int u, float4 (&v)[4]) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int unit = u * 32 + 8 * g + 4 * half;
       v[g] = make_float4(0, 0, 0, 0);
+      if (g_lds) {
+        if (gb && unit + 3 < Hp) {
+          const vn_f32x4 t = gt[(g_local * EBC_VN_GROUP_PITCH) / 16 + unit / 4];
+          v[g] = make_float4(t.x, t.y, t.z, t.w);
+        }
+        continue;
+      }
       if (gb && unit + 3 < ex.H) v[g] = *reinterpret_cast<const float4 *>(gb + unit);
       else if (gb) {
         if (unit < ex.H) v[g].x = gb[unit];
@@ -274,6 +302,33 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
       }
     acc += __shfl_xor(acc, 32, 64);
     if (m < M && half == 0) Y[m] = acc + ex.final_b;
+    return;
+  }
+  if ((O & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)PER_U * 16) {
+    // Rows leave coalesced: an output tile (32 rows x 32 units) is parked in the wave's LDS tile — the weight
+    // buffers are free behind the loop's last barrier — and read back with 8 consecutive lanes per row, so
+    // every 128-byte line of Y is written by one instruction instead of by eight.
+    const LdsF4 yt = (LdsF4)(reinterpret_cast<unsigned char *>(wbuf) + (size_t)wave * 32 * EBC_VN_XROW);
+    const int m0 = (blockIdx.x * NW + wave) * 32;
+    const int piece = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        vn_f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = relu_out ? fmaxf(out[t][0][4 * g + c], 0.0f) : out[t][0][4 * g + c];
+        yt[(col * EBC_VN_XROW + (8 * g + 4 * half) * 4) / 16] = v;  // units 8 g + 4 half .. + 3 of row `col`
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = rsub + 8 * q, unit = t * 32 + 4 * piece;
+        const vn_f32x4 v = yt[(r * EBC_VN_XROW + piece * 16) / 16];
+        if (m0 + r < M && unit + 3 < O) *reinterpret_cast<vn_f32x4 *>(Y + (size_t)(m0 + r) * O + unit) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     return;
   }
   if (m < M) {

@@ -1058,7 +1058,7 @@ int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int rel
   // (attention block 791 -> 692 us per 0.5 M rows; 5.60 -> 5.17 ms per 1024-env decision batch)
   constexpr int NW = (2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4;
   const size_t lds = 2 * (size_t)(TI + TO) * 2 * 2 * 64 * 16 + (size_t)m->L1.out_tiles * 32 * 4 +
-                     (TI >= 2 ? (size_t)NW * 32 * EBC_VN_XROW : 0);  // + the waves' input transposition tiles
+                     (ex.row_bias ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0);  // + the waves' parked group terms
   static size_t raised_dev[64] = {0};  // more than the 64 KB a launch gets by default; a function attribute is per device
   size_t &raised = raised_dev[m->device & 63];
   if (lds > 65536 && lds > raised) {
