@@ -220,12 +220,16 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
   };
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count the asm loads
   __syncthreads();
+  // Shapes whose input fragments + output accumulators leave few of the 256 registers two waves per SIMD get
+  // (7 + 7 tiles: 224): one hidden accumulator instead of two, output tiles two at a time, the group term
+  // read after the hidden MFMAs instead of held across them — the partner wave covers the dependent issue.
+  constexpr bool TIGHT = (TI + TO) * 16 >= 224;
   for (int u = 0; u < hidden_tiles; ++u) {
     const int buf = u & 1;
     // this tile's group term first (its wait, after the first batch of MFMAs below, then also waits for
     // the staging issued behind it — by then that has had those MFMAs' time), then the next tile's weights
     float4 gcur[4];
-    if (GROUP) group_bias(u, gcur);
+    if (GROUP && !TIGHT) group_bias(u, gcur);
     if (u + 1 < hidden_tiles) stage(u + 1, buf ^ 1);
     const uint4 *w = wbuf + (size_t)buf * PER_U + lane;
     auto frag = [&](int blk, int s) {
@@ -253,14 +257,15 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
       for (int s = 0; s < 2; ++s) {
         const Frag2 wf = frag(i, s);
         constexpr int first = 1;  // three MFMAs per step: 1 0 1 | 0 1 0 | ... never the same accumulator twice in a row
-        const int p = ((i * 2 + s) & 1) ? 1 - first : first;
+        const int p = TIGHT ? 0 : (((i * 2 + s) & 1) ? 1 - first : first);
         hacc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.lo, x[i][s][0].hi, hacc[p], 0, 0, 0);
-        hacc[1 - p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].lo, hacc[1 - p], 0, 0, 0);
+        hacc[TIGHT ? 0 : 1 - p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].lo, hacc[TIGHT ? 0 : 1 - p], 0, 0, 0);
         hacc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].hi, hacc[p], 0, 0, 0);
       }
     f32x16 hid;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hid[r] = hacc[0][r] + hacc[1][r];
+    for (int r = 0; r < 16; ++r) hid[r] = TIGHT ? hacc[0][r] : hacc[0][r] + hacc[1][r];
+    if (GROUP && TIGHT) group_bias(u, gcur);
     if (GROUP) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -272,8 +277,8 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int t0 = 0; t0 < TO; t0 += 4) {  // four output tiles at a time: enough independent MFMAs, few registers
-        constexpr int C = 4;
+      for (int t0 = 0; t0 < TO; t0 += (TIGHT ? 2 : 4)) {  // four output tiles at a time: enough independent MFMAs, few registers
+        constexpr int C = TIGHT ? 2 : 4;
         Frag2 wf[C];
 #pragma unroll
         for (int c = 0; c < C; ++c)

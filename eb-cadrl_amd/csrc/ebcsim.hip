@@ -1056,7 +1056,11 @@ int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int rel
   // 8 also where the tiles want more than the 256 registers two waves per SIMD leave each (7 + 7 tiles:
   // a few spilled registers): measured, two waves per SIMD beat one with all its registers
   // (attention block 791 -> 692 us per 0.5 M rows; 5.60 -> 5.17 ms per 1024-env decision batch)
+#ifdef EBC_MLP_NW4_WIDE  // A/B: one wave per SIMD with all its registers for the widest shapes too
+  constexpr int NW = (TI + TO >= 14) ? 4 : ((2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4);
+#else
   constexpr int NW = (2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4;
+#endif
   const size_t lds = 2 * (size_t)(TI + TO) * 2 * 2 * 64 * 16 + (size_t)m->L1.out_tiles * 32 * 4 +
                      (ex.row_bias ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0);  // + the waves' parked group terms
   static size_t raised_dev[64] = {0};  // more than the 64 KB a launch gets by default; a function attribute is per device

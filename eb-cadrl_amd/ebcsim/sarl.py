@@ -116,6 +116,9 @@ class SarlValueNet(object):
                 # (the reference's 200 -> 200 -> 1) stays with torch
                 if (len(self.mlp3) >= 3 and self.mlp3[0][0].shape[1] <= 224 and self.mlp3[1][0].shape[0] <= 224):
                     blocks.append(_NativeMlp2(self.mlp3[:2], idx))
+                    # ... and its last two layers (the reference's 200 -> 200 -> 1) as a block with one output
+                    if len(self.mlp3) == 4 and self.mlp3[2][0].shape[1] <= 224 and self.mlp3[3][0].shape[0] <= 224:
+                        blocks.append(_NativeMlp2(self.mlp3[2:4], idx))
                 self._native = tuple(blocks)
             else:
                 self._native = ()
@@ -230,7 +233,9 @@ class SarlValueNet(object):
             w = (e / e.sum(dim=1, keepdim=True)).unsqueeze(2)
             attended = (w * feat).sum(dim=1)
         joint = torch.cat([self_state, attended], dim=1)
-        if nat is not None and len(nat) > 3:
+        if nat is not None and len(nat) > 4:
+            value = nat[4](nat[3](joint, True), False).squeeze(1)
+        elif nat is not None and len(nat) > 3:
             value = _mlp(nat[3](joint, True), self.mlp3[2:], False).squeeze(1).to(torch.float32)
         else:
             value = _mlp(joint, self.mlp3, False).squeeze(1).to(torch.float32)
