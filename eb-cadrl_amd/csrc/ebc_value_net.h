@@ -273,9 +273,15 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
       }
     }
     Frag2 hf[2];
-    tile_frags(hid, true, hf);
+    if (!TIGHT) tile_frags(hid, true, hf);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+      if (TIGHT) {  // one k-step's fragment at a time: eight registers fewer live across the output MFMAs
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(hid[8 * s + j], 0.0f);
+        hf[s] = split8(v);
+      }
 #pragma unroll
       for (int t0 = 0; t0 < TO; t0 += (TIGHT ? 2 : 4)) {  // four output tiles at a time: enough independent MFMAs, few registers
         constexpr int C = TIGHT ? 2 : 4;
@@ -293,6 +299,7 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
         for (int c = 0; c < C; ++c)
           if (t0 + c < TO) out[t0 + c][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c].hi, hf[s].hi, out[t0 + c][0], 0, 0, 0);
       }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile u + 1 has landed ...
     __syncthreads();                                   // ... and everybody's; buffer `buf` is free
   }
