@@ -104,8 +104,13 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
   const int m = (blockIdx.x * NW + wave) * 32 + col;
   const int hidden_tiles = L1.out_tiles;
-  auto stage = [&](int u, int buf) {  // fragment halves p = wave, wave + NW, ...: one wave instruction each
-    for (int pp = wave; pp < (TI + TO) * 4; pp += NW) {
+  // Weight staging, global -> LDS without registers (global_load_lds, 1 KB per wave instruction).  A hidden tile's
+  // weights are two HALVES with different deadlines: its L1 row block (TI fragments, read by the hidden phase) and
+  // its L2 column block (TO fragments, read by the output phase).  which = 0: L1 block, 1: L2 block.
+  auto stage_half = [&](int u, int which, int buf) {
+    const int first = which ? TI * 4 : 0, count = (which ? TO : TI) * 4;
+    for (int q = wave; q < count; q += NW) {
+      const int pp = first + q;
       const int blk = pp >> 2, s = (pp >> 1) & 1, part = pp & 1;
       const uint4 *src = blk < TI ? L1.frag + ((((size_t)u * TI + blk) * 2 + s) * 2 + part) * PART
                                   : L2.frag + ((((size_t)(blk - TI) * hidden_tiles + u) * 2 + s) * 2 + part) * PART;
@@ -120,12 +125,35 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
                    : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
     }
   };
+  // Pipelining across barriers: a phase ends with a COUNTED wait that leaves the stage issued at its start in
+  // flight (every wave issued at least N_L1 / N_L2 instructions of it; older ones have then landed: one in-order
+  // counter) and a raw s_barrier — __syncthreads() would drain vmcnt to 0, i.e. wait for the newest stage at the
+  // end of the very phase that issued it (the ~36 %-of-peak ceiling of the two-barrier K-step,
+  // cdna_hip_programming.md).  What a phase reads was staged a whole iteration earlier.
+  constexpr int N_L1 = (TI * 4) / NW, N_L2 = (TO * 4) / NW;
+  auto phase_end = [&](bool newest_in_flight, int n_keep) {
+    if (!newest_in_flight) n_keep = 0;
+    switch (n_keep) {  // the count is an immediate
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   // No ordinary global load inside the loop: while a global_load_lds is in flight the compiler waits
   // for ALL outstanding loads at the next use of a load result, and the overlap would be gone.  The
   // hidden biases therefore wait in LDS.
   float *hbias = reinterpret_cast<float *>(wbuf + 2 * PER_U);
   for (int q = threadIdx.x; q < hidden_tiles * 32; q += 64 * NW) hbias[q] = L1.bias[q];
-  stage(0, 0);
+  stage_half(0, 0, 0);
+  stage_half(0, 1, 0);
   // the input tile as B fragments, natural k order: element j of k-step s is k = 16 s + 8 half + j
   Frag2 x[TI][2][1];
   if (TI >= 2 && (K0 & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)PER_U * 16) {
@@ -218,8 +246,13 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
       }
     }
   };
+  // the output biases (ordinary loads) are used HERE: left to the compiler, their wait lands at the accumulators'
+  // first use inside the loop — an `s_waitcnt vmcnt(0)` in every iteration's output phase, which drains the staging
+#pragma unroll
+  for (int t = 0; t < TO; ++t) asm volatile("" : "+v"(out[t][0]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count the asm loads
-  __syncthreads();
+  __syncthreads();                                   // tile 0's weights are in; the input tiles (weight buffer 1) are done with
+  if (hidden_tiles > 1) stage_half(1, 0, 1);         // tile 1's L1 block: read a whole iteration from now
   // Shapes whose input fragments + output accumulators leave few of the 256 registers two waves per SIMD get
   // (7 + 7 tiles: 224): one hidden accumulator instead of two, output tiles two at a time, the group term
   // read after the hidden MFMAs instead of held across them — the partner wave covers the dependent issue.
@@ -230,7 +263,8 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
     // the staging issued behind it — by then that has had those MFMAs' time), then the next tile's weights
     float4 gcur[4];
     if (GROUP && !TIGHT) group_bias(u, gcur);
-    if (u + 1 < hidden_tiles) stage(u + 1, buf ^ 1);
+    const bool more1 = u + 1 < hidden_tiles, more2 = u + 2 < hidden_tiles;
+    if (more1) stage_half(u + 1, 1, buf ^ 1);  // next tile's L2 block: its buffer was read last in the output phase of u - 1
     const uint4 *w = wbuf + (size_t)buf * PER_U + lane;
     auto frag = [&](int blk, int s) {
       const uint4 h = w[((blk * 2 + s) * 2) * PART], l = w[((blk * 2 + s) * 2 + 1) * PART];
@@ -262,6 +296,10 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
         hacc[TIGHT ? 0 : 1 - p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].lo, hacc[TIGHT ? 0 : 1 - p], 0, 0, 0);
         hacc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf.hi, x[i][s][0].hi, hacc[p], 0, 0, 0);
       }
+    // ---- between the phases: this tile's L2 block (staged during the hidden phase of u - 1) has landed; every
+    // wave is done reading this tile's L1 block, so its buffer takes the L1 block of tile u + 2
+    phase_end(more1, N_L2);
+    if (more2) stage_half(u + 2, 0, buf);
     f32x16 hid;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hid[r] = TIGHT ? hacc[0][r] : hacc[0][r] + hacc[1][r];
@@ -300,9 +338,10 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
           if (t0 + c < TO) out[t0 + c][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c].hi, hf[s].hi, out[t0 + c][0], 0, 0, 0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile u + 1 has landed ...
-    __syncthreads();                                   // ... and everybody's; buffer `buf` is free
+    phase_end(more2, N_L1);  // tile u + 1's L1 block (staged during the output phase of u - 1) has landed
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (ex.final_w) {  // third layer with one output: a dot product over the units this lane holds, then the other half's
     float acc = 0.0f;
 #pragma unroll
