@@ -752,6 +752,33 @@ def gen_sarl_rl_memory(ref):
     RVO2_MODE["substitute"] = False
 
 
+def gen_trainer_steps(ref):
+    """Three optimizer steps of the reference's own Trainer (rl/utils/trainer.py:74-100, SGD momentum 0.9) on the
+    RL-mode memory of gen_sarl_rl_memory, every pair in the batch (the DataLoader's shuffle then only permutes the
+    mean), starting from the shipped baseline weights: the losses and the parameters afterwards."""
+    import torch
+    from rl.policy.policy_factory import policy_factory
+    from rl.utils.memory import ReplayMemory
+    from rl.utils.trainer import Trainer
+    name, env_path, overrides, pol_path, weights, case = SARL_RUNS[0]
+    g = np.load(os.path.join(HERE, "sarl_a5_rl_memory.npz"))
+    pol = policy_factory["sarl"]()
+    pol.configure(parsed(open(os.path.join(ref, pol_path)).read()))
+    model = pol.get_model()
+    model.load_state_dict(torch.load(os.path.join(ref, weights)))
+    mem = ReplayMemory(1000)
+    for st, v in zip(g["rl_state"], g["rl_value"]):
+        mem.push((torch.from_numpy(st), torch.Tensor([v])))
+    torch.manual_seed(0)
+    tr = Trainer(model, mem, "cpu", len(mem.memory), "sgd")
+    tr.set_optimizer(0.01)
+    losses = [tr.optimize_batch(1) for _ in range(3)]
+    out = {"loss": np.array(losses), "lr": np.array(0.01), "steps": np.array(3)}
+    for k, v in model.state_dict().items():
+        out["p_" + k] = v.detach().numpy()
+    save("sarl_a5_trainer_steps", **out)
+
+
 def gen_sarl_configs(ref):
     """The env / policy configuration of each SARL run as text (data the reference ships), for the tests
     that drive the facade with a policy OBJECT (which configures itself from such files)."""
@@ -797,7 +824,7 @@ def gen_local_map(ref):
 
 GENERATORS = {"collisions": gen_collisions, "reward": gen_reward, "grid": gen_grid,
               "rotate": gen_rotate, "action_space": gen_action_space, "scenes": gen_scenes,
-              "trajectories": gen_trajectories, "il": gen_il, "known": gen_known_answers, "sarl": gen_sarl, "sarl_rl": gen_sarl_rl_memory, "sarl_configs": gen_sarl_configs,
+              "trajectories": gen_trajectories, "il": gen_il, "known": gen_known_answers, "sarl": gen_sarl, "sarl_rl": gen_sarl_rl_memory, "trainer": gen_trainer_steps, "sarl_configs": gen_sarl_configs,
               "local_map": gen_local_map}
 
 

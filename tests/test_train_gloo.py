@@ -409,3 +409,29 @@ def test_rl_mode_memory_equals_the_reference_explorer_cpu():
 def test_rl_mode_memory_equals_the_reference_explorer_gpu():
     from ebcsim.batched import BatchedEnv
     _rl_memory_against_reference(lambda p, E, N, S: BatchedEnv(p, E, N, S), "cuda:0")
+
+
+def test_optimizer_steps_equal_the_reference_trainer():
+    """rl/utils/trainer.py:74-100: three SGD (momentum 0.9) steps of the reference's own Trainer on the golden
+    RL memory, all pairs per batch, from the shipped weights — this trainer's losses and every parameter
+    afterwards are the reference's (golden: the reference's Trainer + ValueNetwork + ReplayMemory)."""
+    from helpers import GOLDEN, load
+    from ebcsim.train import DataParallelTrainer, DeviceReplay, SarlModule
+    g, t = load("sarl_a5_rl_memory"), load("sarl_a5_trainer_steps")
+    sd = torch.load(os.path.join(GOLDEN, "weights", "sarl_a5_baseline.pth"), map_location="cpu")
+    model = SarlModule(**DIMS)
+    model.load_state_dict(sd)
+    n = len(g["rl_value"])
+    mem = DeviceReplay(n, 5, 13, "cpu")
+    mem.push(torch.from_numpy(g["rl_state"]), torch.from_numpy(g["rl_value"]))
+
+    class All(object):  # the whole memory as the batch, like the golden run
+        def sample(self, bs, generator=None):
+            return mem.states[:n], mem.values[:n]
+    tr = DataParallelTrainer(model, All(), n, "sgd", float(t["lr"]))
+    losses = [tr.optimize_batch(1) for _ in range(int(t["steps"]))]
+    np.testing.assert_allclose(losses, t["loss"], rtol=2e-5)
+    after = model.state_dict()
+    for k in sd:
+        np.testing.assert_allclose(after[k].detach().numpy(), t["p_" + k], atol=2e-7, rtol=2e-5, err_msg=k)
+        assert not np.array_equal(t["p_" + k], sd[k].numpy()) or k.endswith("bias")  # the steps moved the weights
