@@ -95,12 +95,20 @@ __device__ __forceinline__ void tile_frags(const f32x16 &acc, bool relu, Frag2 (
 // NW waves per workgroup: 8 (two per SIMD sharing one copy of the weights) when the tiles fit 256
 // registers and the double buffer is too big for two workgroups per CU; else 4 (two workgroups per CU when
 // LDS allows, one wave per SIMD with up to 512 registers when the tiles need them).
-template <int TI, int TO, int NW, bool GROUP>
-__global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) void mlp2_split_wg_kernel(const float *X, int M, int K0, PackedLayer L1,
+// LEAN: the L2 halves share ONE LDS slot (staged at the start of the hidden phase of their own tile) instead of
+// two: 2 A + B instead of 2 A + 2 B bytes, which lets TWO independent 4-wave workgroups live on a CU where one
+// lock-stepped 8-wave workgroup did (the 17 -> 300 -> 200 shape, whose full layout already fits twice, is the most
+// efficient of the three for that reason: its two workgroups drift apart and fill each other's waits).
+template <int TI, int TO, int NW, bool GROUP, bool LEAN = false>
+__global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 : 1)) void mlp2_split_wg_kernel(const float *X, int M, int K0, PackedLayer L1,
                                                            PackedLayer L2, int relu_out, float *Y, int O, MlpExtra ex) {
-  extern __shared__ uint4 wbuf[];  // [2][PER_U] weights, then the hidden layer's biases
+  extern __shared__ uint4 wbuf[];  // weights: A0 | B0 | A1 | B1 (LEAN: A0 | B | A1), then the hidden layer's biases
   constexpr int PART = 64;                          // uint4 per fragment half (hi or lo) = 1 KB
-  constexpr int PER_U = (TI + TO) * 2 * 2 * PART;   // uint4 per hidden tile: its L1 row block + its L2 column block
+  constexpr int A_SIZE = TI * 2 * 2 * PART, B_SIZE = TO * 2 * 2 * PART;  // uint4 per L1 / L2 half
+  constexpr int PER_U = LEAN ? (2 * A_SIZE + B_SIZE + 1) / 2 : A_SIZE + B_SIZE;  // half the weight region, in uint4
+  constexpr int XCAP = LEAN ? A_SIZE : A_SIZE + B_SIZE;                   // uint4 free for the input tiles (from A1 on)
+  auto off_a = [](int buf) { return buf ? A_SIZE + B_SIZE : 0; };
+  auto off_b = [](int buf) { return LEAN ? A_SIZE : (buf ? 2 * A_SIZE + B_SIZE : A_SIZE); };
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
   const int m = (blockIdx.x * NW + wave) * 32 + col;
   const int hidden_tiles = L1.out_tiles;
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
       const int blk = pp >> 2, s = (pp >> 1) & 1, part = pp & 1;
       const uint4 *src = blk < TI ? L1.frag + ((((size_t)u * TI + blk) * 2 + s) * 2 + part) * PART
                                   : L2.frag + ((((size_t)(blk - TI) * hidden_tiles + u) * 2 + s) * 2 + part) * PART;
-      uint4 *dst = wbuf + (size_t)buf * PER_U + (size_t)pp * PART;
+      uint4 *dst = wbuf + (which ? off_b(buf) + (size_t)q * PART : off_a(buf) + (size_t)q * PART);
       // As an asm statement: the builtin makes the compiler drain every outstanding load before the
       // next LDS read (it cannot tell the two buffers apart), which is the overlap this kernel is
       // built for.  M0 = the wave-uniform LDS byte address; each lane supplies its source address.
@@ -156,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
   stage_half(0, 1, 0);
   // the input tile as B fragments, natural k order: element j of k-step s is k = 16 s + 8 half + j
   Frag2 x[TI][2][1];
-  if (TI >= 2 && (K0 & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)PER_U * 16) {
+  if (TI >= 2 && (K0 & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)XCAP * 16) {
     // Wide inputs (the 200-float h1 rows of mlp2 / attention) through LDS.  A lane needs ITS row, 8 consecutive
     // floats per k-step: read straight from memory that is 28 16-byte loads per lane at a row stride, every
     // 128-byte line touched by eight different wave instructions with 200+ KB per CU in flight — the lines
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
     // one row's 128 bytes (each line exactly once), the wave parks the block in its own LDS tile (row pitch
     // 144 B: the 16-byte reads of 16 lanes then fall in 16 different bank groups) and reads it back row per lane.
     // the tiles live in weight buffer 1: nothing is staged into it before the barrier in front of the loop
-    const LdsF4 xt = (LdsF4)(reinterpret_cast<unsigned char *>(wbuf + PER_U) + (size_t)wave * 32 * EBC_VN_XROW);
+    const LdsF4 xt = (LdsF4)(reinterpret_cast<unsigned char *>(wbuf + A_SIZE + B_SIZE) + (size_t)wave * 32 * EBC_VN_XROW);
     const int m0 = (blockIdx.x * NW + wave) * 32;
     const int piece = lane & 7, rsub = lane >> 3;
 #pragma unroll
@@ -264,10 +272,15 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
     float4 gcur[4];
     if (GROUP && !TIGHT) group_bias(u, gcur);
     const bool more1 = u + 1 < hidden_tiles, more2 = u + 2 < hidden_tiles;
-    if (more1) stage_half(u + 1, 1, buf ^ 1);  // next tile's L2 block: its buffer was read last in the output phase of u - 1
-    const uint4 *w = wbuf + (size_t)buf * PER_U + lane;
+    if (LEAN) {
+      if (u > 0) stage_half(u, 1, buf);        // THIS tile's L2 block into the one slot, free since the last barrier
+    } else if (more1) {
+      stage_half(u + 1, 1, buf ^ 1);           // next tile's L2 block: its buffer was read last in the output phase of u - 1
+    }
+    const uint4 *wa = wbuf + off_a(buf) + lane, *wb = wbuf + off_b(buf) + lane;
     auto frag = [&](int blk, int s) {
-      const uint4 h = w[((blk * 2 + s) * 2) * PART], l = w[((blk * 2 + s) * 2 + 1) * PART];
+      const uint4 *w = blk < TI ? wa + ((blk * 2 + s) * 2) * PART : wb + (((blk - TI) * 2 + s) * 2) * PART;
+      const uint4 h = w[0], l = w[PART];
       Frag2 f;
       f.hi = *reinterpret_cast<const bf16x8 *>(&h);
       f.lo = *reinterpret_cast<const bf16x8 *>(&l);
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
       }
     // ---- between the phases: this tile's L2 block (staged during the hidden phase of u - 1) has landed; every
     // wave is done reading this tile's L1 block, so its buffer takes the L1 block of tile u + 2
-    phase_end(more1, N_L2);
+    phase_end(!LEAN && more1, N_L2);  // LEAN: this tile's L2 block is the newest stage: wait for everything
     if (more2) stage_half(u + 2, 0, buf);
     f32x16 hid;
 #pragma unroll
@@ -355,7 +368,7 @@ __global__ __launch_bounds__(64 * NW, (((TI + TO) * 16 + 64 <= 256) ? 2 : 1)) vo
     if (m < M && half == 0) Y[m] = acc + ex.final_b;
     return;
   }
-  if ((O & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)PER_U * 16) {
+  if ((O & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)PER_U * 2 * 16) {
     // Rows leave coalesced: an output tile (32 rows x 32 units) is parked in the wave's LDS tile — the weight
     // buffers are free behind the loop's last barrier — and read back with 8 consecutive lanes per row, so
     // every 128-byte line of Y is written by one instruction instead of by eight.

@@ -1050,34 +1050,45 @@ int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool ac
   return EBC_OK;
 }
 
-template <int TI, int TO>
-int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
-  // NW waves per workgroup, a 32-row tile each; the weights of one hidden tile twice in LDS
-  // 8 also where the tiles want more than the 256 registers two waves per SIMD leave each (7 + 7 tiles:
-  // a few spilled registers): measured, two waves per SIMD beat one with all its registers
-  // (attention block 791 -> 692 us per 0.5 M rows; 5.60 -> 5.17 ms per 1024-env decision batch)
-#ifdef EBC_MLP_NW4_WIDE  // A/B: one wave per SIMD with all its registers for the widest shapes too
-  constexpr int NW = (TI + TO >= 14) ? 4 : ((2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4);
-#else
-  constexpr int NW = (2 * (TI + TO) * 4096 > 80 * 1024) ? 8 : 4;
-#endif
-  const size_t lds = 2 * (size_t)(TI + TO) * 2 * 2 * 64 * 16 + (size_t)m->L1.out_tiles * 32 * 4 +
+template <int TI, int TO, int NW, bool LEAN>
+int launch_mlp2_shape(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
+  const size_t weights = LEAN ? (size_t)(2 * TI + TO) * 4096 : 2 * (size_t)(TI + TO) * 4096;
+  const size_t lds = (weights + 31) / 32 * 32 + (size_t)m->L1.out_tiles * 32 * 4 +
                      (ex.row_bias ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0);  // + the waves' parked group terms
-  static size_t raised_dev[64] = {0};  // more than the 64 KB a launch gets by default; a function attribute is per device
-  size_t &raised = raised_dev[m->device & 63];
+  static size_t raised_dev[64][2] = {{0}};  // more than the 64 KB a launch gets by default; a function attribute is per device
+  size_t &raised = raised_dev[m->device & 63][ex.row_bias ? 1 : 0];
   if (lds > 65536 && lds > raised) {
-    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ex.row_bias)
+      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else
+      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, false, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = lds;
   }
   constexpr int rows = 32 * NW;
   const dim3 grid((unsigned)((M + rows - 1) / rows)), block(64 * NW);
   if (ex.row_bias)
-    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, true>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
+    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
   else
-    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, false>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
+    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, false, LEAN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
+}
+
+template <int TI, int TO>
+int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
+  // Workgroup shape by LDS: the full layout (both halves of the weights double-buffered) twice per CU where it
+  // fits (4 waves each); else the lean layout (one slot for the L2 halves) twice per CU where THAT fits: two
+  // independent 4-wave workgroups fill each other's waits, which one lock-stepped 8-wave workgroup cannot; else
+  // 8 waves sharing one full layout (two waves per SIMD with 256 registers each: measured faster than 4 waves
+  // with 512 for the widest shape, spills included).
+  constexpr size_t full = 2 * (size_t)(TI + TO) * 4096, lean = (size_t)(2 * TI + TO) * 4096, half_cu = 78 * 1024;
+#ifdef EBC_MLP_NO_LEAN
+  constexpr bool use_lean = false;
+#else
+  constexpr bool use_lean = full > half_cu && lean <= half_cu;
+#endif
+  if (use_lean) return launch_mlp2_shape<TI, TO, 4, true>(m, st, x, M, relu_out, y, ex);
+  return launch_mlp2_shape<TI, TO, (full > 80 * 1024 ? 8 : 4), false>(m, st, x, M, relu_out, y, ex);
 }
 
 template <int TI>
