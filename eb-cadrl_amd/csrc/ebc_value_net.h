@@ -99,15 +99,18 @@ __device__ __forceinline__ void tile_frags(const f32x16 &acc, bool relu, Frag2 (
 // two: 2 A + B instead of 2 A + 2 B bytes, which lets TWO independent 4-wave workgroups live on a CU where one
 // lock-stepped 8-wave workgroup did (the 17 -> 300 -> 200 shape, whose full layout already fits twice, is the most
 // efficient of the three for that reason: its two workgroups drift apart and fill each other's waits).
-template <int TI, int TO, int NW, bool GROUP, bool LEAN = false>
+// LEAN 2: ONE slot for the L1 halves too (A | B): every half is staged one phase ahead into the slot the barrier just
+// passed has freed; for the shape whose lean layout is still too big to fit a CU twice (7 + 7 tiles).
+template <int TI, int TO, int NW, bool GROUP, int LEAN = 0>
 __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 : 1)) void mlp2_split_wg_kernel(const float *X, int M, int K0, PackedLayer L1,
                                                            PackedLayer L2, int relu_out, float *Y, int O, MlpExtra ex) {
   extern __shared__ uint4 wbuf[];  // weights: A0 | B0 | A1 | B1 (LEAN: A0 | B | A1), then the hidden layer's biases
   constexpr int PART = 64;                          // uint4 per fragment half (hi or lo) = 1 KB
   constexpr int A_SIZE = TI * 2 * 2 * PART, B_SIZE = TO * 2 * 2 * PART;  // uint4 per L1 / L2 half
-  constexpr int PER_U = LEAN ? (2 * A_SIZE + B_SIZE + 1) / 2 : A_SIZE + B_SIZE;  // half the weight region, in uint4
-  constexpr int XCAP = LEAN ? A_SIZE : A_SIZE + B_SIZE;                   // uint4 free for the input tiles (from A1 on)
-  auto off_a = [](int buf) { return buf ? A_SIZE + B_SIZE : 0; };
+  constexpr int PER_U = LEAN == 2 ? (A_SIZE + B_SIZE + 1) / 2 : LEAN ? (2 * A_SIZE + B_SIZE + 1) / 2 : A_SIZE + B_SIZE;  // half the weight region, in uint4
+  // uint4 free for the input tiles: from A1 on; LEAN 2 has no idle slot: the whole region, weights staged afterwards
+  constexpr int XCAP = LEAN == 2 ? A_SIZE + B_SIZE : LEAN ? A_SIZE : A_SIZE + B_SIZE;
+  auto off_a = [](int buf) { return (LEAN != 2 && buf) ? A_SIZE + B_SIZE : 0; };
   auto off_b = [](int buf) { return LEAN ? A_SIZE : (buf ? 2 * A_SIZE + B_SIZE : A_SIZE); };
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
   const int m = (blockIdx.x * NW + wave) * 32 + col;
@@ -160,8 +163,10 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
   // hidden biases therefore wait in LDS.
   float *hbias = reinterpret_cast<float *>(wbuf + 2 * PER_U);
   for (int q = threadIdx.x; q < hidden_tiles * 32; q += 64 * NW) hbias[q] = L1.bias[q];
-  stage_half(0, 0, 0);
-  stage_half(0, 1, 0);
+  if (LEAN != 2) {
+    stage_half(0, 0, 0);
+    stage_half(0, 1, 0);
+  }
   // the input tile as B fragments, natural k order: element j of k-step s is k = 16 s + 8 half + j
   Frag2 x[TI][2][1];
   if (TI >= 2 && (K0 & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)XCAP * 16) {
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
     // one row's 128 bytes (each line exactly once), the wave parks the block in its own LDS tile (row pitch
     // 144 B: the 16-byte reads of 16 lanes then fall in 16 different bank groups) and reads it back row per lane.
     // the tiles live in weight buffer 1: nothing is staged into it before the barrier in front of the loop
-    const LdsF4 xt = (LdsF4)(reinterpret_cast<unsigned char *>(wbuf + A_SIZE + B_SIZE) + (size_t)wave * 32 * EBC_VN_XROW);
+    const LdsF4 xt = (LdsF4)(reinterpret_cast<unsigned char *>(wbuf + (LEAN == 2 ? 0 : A_SIZE + B_SIZE)) + (size_t)wave * 32 * EBC_VN_XROW);
     const int m0 = (blockIdx.x * NW + wave) * 32;
     const int piece = lane & 7, rsub = lane >> 3;
 #pragma unroll
@@ -260,7 +265,14 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
   for (int t = 0; t < TO; ++t) asm volatile("" : "+v"(out[t][0]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler does not count the asm loads
   __syncthreads();                                   // tile 0's weights are in; the input tiles (weight buffer 1) are done with
-  if (hidden_tiles > 1) stage_half(1, 0, 1);         // tile 1's L1 block: read a whole iteration from now
+  if (LEAN == 2) {  // the input tiles had the weight region: tile 0's weights now
+    stage_half(0, 0, 0);
+    stage_half(0, 1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  } else if (hidden_tiles > 1) {
+    stage_half(1, 0, 1);                             // tile 1's L1 block: read a whole iteration from now
+  }
   // Shapes whose input fragments + output accumulators leave few of the 256 registers two waves per SIMD get
   // (7 + 7 tiles: 224): one hidden accumulator instead of two, output tiles two at a time, the group term
   // read after the hidden MFMAs instead of held across them — the partner wave covers the dependent issue.
@@ -312,7 +324,11 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
     // ---- between the phases: this tile's L2 block (staged during the hidden phase of u - 1) has landed; every
     // wave is done reading this tile's L1 block, so its buffer takes the L1 block of tile u + 2
     phase_end(!LEAN && more1, N_L2);  // LEAN: this tile's L2 block is the newest stage: wait for everything
-    if (more2) stage_half(u + 2, 0, buf);
+    if (LEAN == 2) {
+      if (more1) stage_half(u + 1, 0, 0);  // the one L1 slot is free: next tile's L1 block, due after the output phase
+    } else if (more2) {
+      stage_half(u + 2, 0, buf);
+    }
     f32x16 hid;
 #pragma unroll
     for (int r = 0; r < 16; ++r) hid[r] = TIGHT ? hacc[0][r] : hacc[0][r] + hacc[1][r];
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
           if (t0 + c < TO) out[t0 + c][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c].hi, hf[s].hi, out[t0 + c][0], 0, 0, 0);
       }
     }
-    phase_end(more2, N_L1);  // tile u + 1's L1 block (staged during the output phase of u - 1) has landed
+    phase_end(LEAN != 2 && more2, N_L1);  // tile u + 1's L1 block (staged during the output phase of u - 1) has landed
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

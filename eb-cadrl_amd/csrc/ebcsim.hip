@@ -1050,9 +1050,9 @@ int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool ac
   return EBC_OK;
 }
 
-template <int TI, int TO, int NW, bool LEAN>
+template <int TI, int TO, int NW, int LEAN>
 int launch_mlp2_shape(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
-  const size_t weights = LEAN ? (size_t)(2 * TI + TO) * 4096 : 2 * (size_t)(TI + TO) * 4096;
+  const size_t weights = LEAN == 2 ? (size_t)(TI + TO) * 4096 : LEAN ? (size_t)(2 * TI + TO) * 4096 : 2 * (size_t)(TI + TO) * 4096;
   const size_t lds = (weights + 31) / 32 * 32 + (size_t)m->L1.out_tiles * 32 * 4 +
                      (ex.row_bias ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0);  // + the waves' parked group terms
   static size_t raised_dev[64][2] = {{0}};  // more than the 64 KB a launch gets by default; a function attribute is per device
@@ -1087,8 +1087,12 @@ int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int rel
 #else
   constexpr bool use_lean = full > half_cu && lean <= half_cu;
 #endif
-  if (use_lean) return launch_mlp2_shape<TI, TO, 4, true>(m, st, x, M, relu_out, y, ex);
-  return launch_mlp2_shape<TI, TO, (full > 80 * 1024 ? 8 : 4), false>(m, st, x, M, relu_out, y, ex);
+  if (use_lean) return launch_mlp2_shape<TI, TO, 4, 1>(m, st, x, M, relu_out, y, ex);
+#ifdef EBC_MLP_LEAN2  // A/B: one slot per half for shapes whose lean layout does not fit twice (7 + 7 tiles)
+  constexpr size_t lean2 = (size_t)(TI + TO) * 4096;
+  if (full > half_cu && lean2 + 16 * 1024 <= half_cu) return launch_mlp2_shape<TI, TO, 4, 2>(m, st, x, M, relu_out, y, ex);
+#endif
+  return launch_mlp2_shape<TI, TO, (full > 80 * 1024 ? 8 : 4), 0>(m, st, x, M, relu_out, y, ex);
 }
 
 template <int TI>
