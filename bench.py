@@ -189,9 +189,14 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 def ebc_scene_slice(batch, n):
     """The first n scenes of a SceneBatch."""
+    return ebc_scene_slice_range(batch, 0, n)
+
+
+def ebc_scene_slice_range(batch, lo, hi):
+    """Scenes [lo, hi) of a SceneBatch."""
     from ebcsim import scene as ebc_scene
-    return ebc_scene.SceneBatch(n, batch.N, batch.S, *[
-        None if getattr(batch, k) is None else getattr(batch, k)[:n] for k in (
+    return ebc_scene.SceneBatch(hi - lo, batch.N, batch.S, *[
+        None if getattr(batch, k) is None else getattr(batch, k)[lo:hi] for k in (
             "n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
             "n_static", "spx", "spy", "sradius", "grid", "robot")])
 
