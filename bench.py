@@ -258,6 +258,36 @@ def also_kernels(env, batch, dev):
     except Exception as e:
         out.append({"kernel": "ebc_step_k", "error": repr(e)})
     try:
+        # The same batch as TWO independent sub-batches, each a handle on its own HIP stream (scenes are independent:
+        # the split is exact): launches of the two overlap, one's tail under the other's head.  Reported beside the
+        # headline, which stays one launch per step of the whole batch (per-launch roofline comparable across rounds).
+        from ebcsim.batched import BatchedEnv as _BE
+        half = env.E // 2
+        subs, souts = [], []
+        for lo in (0, half):
+            e2 = _BE(env.params, half, batch.N, batch.S, device=dev.index or 0)  # keeps its private stream
+            e2.reset(ebc_scene_slice_range(batch, lo, lo + half))
+            subs.append(e2)
+            souts.append(e2.alloc_step_outputs(("reward", "done", "info", "obs_rotated")))
+        kw2 = dict(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=_abi.FLAG_AUTO_RESET)
+
+        def run(n):
+            for _ in range(n):
+                for e2, o2 in zip(subs, souts):
+                    e2.step_device(o2, **kw2)
+            for e2 in subs:
+                e2.synchronize()
+        run(50)
+        import time as _t
+        t0 = _t.perf_counter()
+        run(400)
+        dt = _t.perf_counter() - t0
+        out.append({"kernel": "two sub-batches of %d envs on two HIP streams, one orca_step_kernel launch each per step" % half,
+                    "us_per_step": dt / 400 * 1e6, "agent_steps_per_s": float(batch.n_humans[:2 * half].sum()) * 400 / dt})
+        del subs, souts
+    except Exception as e:
+        out.append({"kernel": "two sub-batches on two streams", "error": repr(e)})
+    try:
         # One robot decision per env for 1024 envs: 81-action look-ahead sweep + the SARL value network (the
         # architecture of the reference's shipped eb-cadrl weights, data/eb-cadrl/policy_x2_agent_type.config;
         # random-init weights) on 1024 x 81 pairs x R rows + top-2 refinement + argmax
