@@ -194,8 +194,10 @@ class SarlValueNet(object):
         else:
             h1 = _mlp(rows.reshape(B * R, T), self.mlp1, True)
             feat = _mlp(h1, self.mlp2, False).view(B, R, -1)
-        fused = (nat is not None and h1.shape[1] % 4 == 0 and feat.shape[2] % 4 == 0
-                 and feat.shape[2] <= 256)  # the pair glue as two HIP kernels
+        # the pair glue as two HIP kernels (plain float32 arithmetic: also behind the float32 GEMMs of the exact pass,
+        # where they replace a dozen element-wise launches)
+        fused = ((nat is not None or (exact and rows.is_cuda and not torch.is_grad_enabled()))
+                 and h1.shape[1] % 4 == 0 and feat.shape[2] % 4 == 0 and feat.shape[2] <= 256)
         nv64 = None if n_valid is None else n_valid.to(torch.int64).contiguous()
         if fused or n_valid is None:
             valid = None
