@@ -1357,6 +1357,30 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
   if (EBC_ROLE_MASK & 8) state_role(p_in, s_in, io_in, L, (int)b, g.rows_blocks != 0, g.epoch, lane);
 }
 
+// Discounted returns of a rollout window, one thread per env walking its K steps backwards (explorer.py:159-170,
+// :82-92): see ebc_il_targets in include/ebcsim.h.
+__global__ __launch_bounds__(256) void il_targets_kernel(const double *reward, const uint8_t *done, const uint8_t *info, int K,
+                                                         int E, double gamma_bar, double *values, uint8_t *keep) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  double run = 0.0;
+  uint8_t closed = 0;
+  for (int t = K - 1; t >= 0; --t) {
+    const size_t q = (size_t)t * E + e;
+    const double r = reward[q];
+    if (done[q]) {
+      const uint8_t c = info[q];
+      run = r;
+      closed = (c == EBC_INFO_REACH_GOAL || c == EBC_INFO_COLLISION_OBSTACLE || c == EBC_INFO_COLLISION_ADULT ||
+                c == EBC_INFO_COLLISION_BICYCLE || c == EBC_INFO_COLLISION_CHILD) ? 1 : 0;
+    } else {
+      run = r + gamma_bar * run;
+    }
+    values[q] = run;
+    keep[q] = closed;
+  }
+}
+
 // Observation rows that exist per env (humans + static obstacles as pedestrians, env.py:381-382, :457-458):
 // what the value network's per-pair kernels mask with.  Read from the device state, so it follows restarts
 // from a ragged scene pool.

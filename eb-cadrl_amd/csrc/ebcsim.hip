@@ -934,6 +934,15 @@ int ebc_row_counts(void *handle, int location, long long *n_rows) {
   return EBC_OK;
 }
 
+int ebc_il_targets(void *stream, const double *reward, const uint8_t *done, const uint8_t *info, int K, int E,
+                   double gamma_bar, double *values, uint8_t *keep) {
+  if (!reward || !done || !info || !values || !keep || K <= 0 || E <= 0) return fail(EBC_ERR_INVALID, "il_targets arguments");
+  hipLaunchKernelGGL(ebc::il_targets_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reward, done,
+                     info, K, E, gamma_bar, values, keep);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
 int ebc_get_state(void *handle, const EbcStateView *v) {
   Handle *h;
   int rc = check_handle(handle, &h);

@@ -30,6 +30,8 @@ SYMBOLS = {
     "ebc_step_k": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_row_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ebc_il_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
+                                 C.c_void_p, C.c_void_p]),
     "ebc_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "ebc_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ebc_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

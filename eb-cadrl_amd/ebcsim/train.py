@@ -155,6 +155,18 @@ def il_value_targets(rewards, done, gamma_bar, info=None):
     stores whole episodes (explorer.py:33-92) — and, when the steps' info codes are given, ended in
     ReachGoal or a collision (`stored_episode`)."""
     T = rewards.shape[0]
+    if (rewards.is_cuda and info is not None and rewards.dtype == torch.float64 and rewards.dim() == 2
+            and done.dtype == torch.uint8 and info.dtype == torch.uint8):
+        # one thread per env walks its window backwards (libebcsim ebc_il_targets): the T-iteration torch loop
+        # below was most of an imitation-learning rollout's wall time
+        from . import _capi
+        rewards, done, info = rewards.contiguous(), done.contiguous(), info.contiguous()
+        values = torch.empty_like(rewards)
+        keep8 = torch.empty_like(done)
+        _capi.check(_capi.lib().ebc_il_targets(torch.cuda.current_stream(rewards.device).cuda_stream, rewards.data_ptr(),
+                                               done.data_ptr(), info.data_ptr(), int(T), int(rewards.shape[1]), float(gamma_bar),
+                                               values.data_ptr(), keep8.data_ptr()))
+        return values, keep8.bool()
     values = torch.zeros_like(rewards)
     keep = torch.zeros_like(done, dtype=torch.bool)
     run = torch.zeros_like(rewards[0])

@@ -292,6 +292,14 @@ int ebc_get_state(void *handle, const EbcStateView *view);
  * auto-reset restarts from a scene pool whose scenes differ in size. */
 int ebc_row_counts(void *handle, int location, long long *n_rows);
 
+/* Imitation-learning value targets of a rollout window (rl/utils/explorer.py:159-170 over the episodes of
+ * ebc_step_k's outputs): value[t][e] = sum over the rest of ITS episode of gamma_bar^(t' - t) reward[t'][e], walked
+ * backwards per env; keep[t][e] = 1 when that episode ended inside the window in ReachGoal or a collision (the
+ * reference stores whole episodes, successes and collisions only: explorer.py:82-92).  reward float64, done / info
+ * uint8 [K][E] (device), values float64 [K][E], keep uint8 [K][E]; stream: hipStream_t. */
+int ebc_il_targets(void *stream, const double *reward, const uint8_t *done, const uint8_t *info, int K, int E,
+                   double gamma_bar, double *values, uint8_t *keep);
+
 /* Geometry of the handle (E, N, S, T, G). */
 int ebc_dims(void *handle, int32_t out[5]);
 

@@ -435,3 +435,23 @@ def test_optimizer_steps_equal_the_reference_trainer():
     for k in sd:
         np.testing.assert_allclose(after[k].detach().numpy(), t["p_" + k], atol=2e-7, rtol=2e-5, err_msg=k)
         assert not np.array_equal(t["p_" + k], sd[k].numpy()) or k.endswith("bias")  # the steps moved the weights
+
+
+@pytest.mark.gpu
+def test_il_targets_kernel_equals_the_host_scan():
+    """ebc_il_targets (one thread per env, backwards over the window) against the torch scan it replaces on the
+    device path — itself pinned on the reference's Explorer memory (test_imitation_learning_targets_match_reference)."""
+    from ebcsim import _abi
+    from ebcsim.train import il_value_targets
+    g = torch.Generator().manual_seed(3)
+    T, E = 57, 333
+    r = torch.rand(T, E, generator=g, dtype=torch.float64) - 0.3
+    codes = torch.tensor([_abi.INFO_NOTHING, _abi.INFO_DANGER, _abi.INFO_REACH_GOAL, _abi.INFO_COLLISION_ADULT,
+                          _abi.INFO_COLLISION_CHILD, _abi.INFO_TIMEOUT, _abi.INFO_COLLISION_OBSTACLE], dtype=torch.uint8)
+    pick = torch.randint(0, 40, (T, E), generator=g)
+    info = torch.where(pick < len(codes), codes[pick.clamp(max=len(codes) - 1)], torch.zeros((), dtype=torch.uint8))
+    done = ((info == _abi.INFO_REACH_GOAL) | (info >= _abi.INFO_COLLISION_OBSTACLE)).to(torch.uint8)
+    v_host, k_host = il_value_targets(r, done, 0.93, info)              # CPU tensors: the torch scan
+    v_dev, k_dev = il_value_targets(r.cuda(), done.cuda(), 0.93, info.cuda())  # CUDA tensors: the kernel
+    assert torch.equal(k_dev.cpu(), k_host)
+    torch.testing.assert_close(v_dev.cpu(), v_host, atol=1e-12, rtol=0)
