@@ -18,6 +18,7 @@
 
 #include "ebc_device.h"
 #include "ebc_orca_group.h"
+#include "ebc_scene_gen.h"
 
 namespace ebc {
 
@@ -617,7 +618,6 @@ __device__ __forceinline__ int service_env(const EbcParams &p_early, const DevSt
   const StepIO &io = io_early;
   double (&sh_cand)[3][EBC_WAVE] = X.cand;
   double (&sh_ract)[EBC_WAVE][2] = X.ract;
-  const double dt = p.time_step;
   grid_slot = (m.leader && s.pool.grid) ? s.grid_scene[m.ee] : 0;
   pin(grid_slot);
   const int epb_env = EBC_WAVE / s.N;                     // envs per wave
@@ -1223,13 +1223,15 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
       orca_pref_from(dx, dy, dist, prefx, prefy);
       typedef float v4f __attribute__((ext_vector_type(4)));
       const v4f t0 = {(float)h.px, (float)h.py, (float)ax, (float)ay}, t1 = {tile_rad, tile_max, prefx, prefy};
-      s.px[m.k] = h.px;
-      s.py[m.k] = h.py;
-      s.vx[m.k] = ax;
-      s.vy[m.k] = ay;
-      s.arrival[m.k] = h.arrival;
-      *reinterpret_cast<v4f *>(tile) = t0;
-      *reinterpret_cast<v4f *>(tile + 1) = t1;
+      // streaming stores: nothing reads these again in this launch, and what is not left dirty in the L2s is not
+      // waiting for the write-back at the end of the launch (-0.2 us per step, profiles/r02_state_nt_ab.txt)
+      __builtin_nontemporal_store(h.px, s.px + m.k);
+      __builtin_nontemporal_store(h.py, s.py + m.k);
+      __builtin_nontemporal_store(ax, s.vx + m.k);
+      __builtin_nontemporal_store(ay, s.vy + m.k);
+      __builtin_nontemporal_store(h.arrival, s.arrival + m.k);
+      __builtin_nontemporal_store(t0, reinterpret_cast<v4f *>(tile));
+      __builtin_nontemporal_store(t1, reinterpret_cast<v4f *>(tile + 1));
     }
     if (m.leader) s.time[m.ee] = tnew;  // the robot's next state is in robot_n already (ENV)
   } else {
@@ -1355,6 +1357,20 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
   }
   b -= g.rows_blocks;
   if (EBC_ROLE_MASK & 8) state_role(p_in, s_in, io_in, L, (int)b, g.rows_blocks != 0, g.epoch, lane);
+}
+
+// SceneGenerator.generate_random_scene for n seeds, one lane per scene (ebc_scene_gen.h): `d` holds the base of
+// arrays shaped like an EbcScene's, `mt` n MT19937 states word-major (lanes of a wave touch consecutive words).
+__global__ __launch_bounds__(64) void scene_gen_kernel(EbcSceneGen c, const uint32_t *seeds, uint32_t seed0, int n, int N, int S,
+                                                        int G, SceneRow d, uint32_t *mt, int *status) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const size_t k = (size_t)r * N, q = (size_t)r * (S ? S : 1);
+  const SceneRow o = {d.n_humans + r, d.px + k, d.py + k, d.vx + k, d.vy + k, d.gx + k, d.gy + k, d.radius + k, d.v_pref + k,
+                      d.type + k, d.n_static + r, d.spx + q, d.spy + q, d.sradius + q,
+                      d.grid ? d.grid + (size_t)r * G * 2 : nullptr, d.robot + (size_t)r * 9};
+  const int st = generate_scene_row(c, seeds ? seeds[r] : seed0 + (uint32_t)r, mt + r, (size_t)n, o, N, S, G);
+  if (st) atomicOr(status, st);
 }
 
 // Discounted returns of a rollout window, one thread per env walking its K steps backwards (explorer.py:159-170,

@@ -308,7 +308,8 @@ int alloc_pool(Handle *h, int P) {
 }
 
 // Copy rows of `sc` to rows `ids` (or 0..n-1) of `d`.
-int upload_scene(Handle *h, const EbcScene *sc, const int32_t *ids, const SceneDst &d, bool with_grid) {
+int upload_scene(Handle *h, const EbcScene *sc, const int32_t *ids, const SceneDst &d, bool with_grid,
+                 hipMemcpyKind kind = hipMemcpyHostToDevice) {
   const int n = sc->n, N = h->s.N, S = h->s.S, G = h->s.G;
   bool contiguous = true;
   if (ids)
@@ -318,11 +319,11 @@ int upload_scene(Handle *h, const EbcScene *sc, const int32_t *ids, const SceneD
     if (!src) return EBC_OK;
     if (contiguous) {
       const int e0 = ids ? ids[0] : 0;
-      HIP_TRY(hipMemcpy((char *)dst_base + (size_t)e0 * row_bytes, src, (size_t)n * row_bytes, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy((char *)dst_base + (size_t)e0 * row_bytes, src, (size_t)n * row_bytes, kind));
     } else {
       for (int r = 0; r < n; ++r)
         HIP_TRY(hipMemcpy((char *)dst_base + (size_t)ids[r] * row_bytes, (const char *)src + (size_t)r * row_bytes,
-                          row_bytes, hipMemcpyHostToDevice));
+                          row_bytes, kind));
     }
     return EBC_OK;
   };
@@ -343,8 +344,11 @@ int upload_scene(Handle *h, const EbcScene *sc, const int32_t *ids, const SceneD
   if (sc->grid) {
     UP_(d.grid, sc->grid, grow);
   } else if (with_grid) {  // these rows get a free map
+    const hipMemcpyKind scene_kind = kind;
+    kind = hipMemcpyHostToDevice;
     std::vector<uint64_t> zeros((size_t)n * G * 2, 0);
     UP_(d.grid, zeros.data(), grow);
+    kind = scene_kind;
   }
 #undef UP_
   return EBC_OK;
@@ -526,12 +530,10 @@ int ebc_dims(void *handle, int32_t out[5]) {
   return EBC_OK;
 }
 
-int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *sc) {
-  Handle *h;
-  int rc = check_handle(handle, &h);
-  if (rc) return rc;
+// env.reset of the listed envs from `sc`, whose arrays are on the host (ebc_reset) or on the device (ebc_generate_reset)
+static int reset_impl(Handle *h, const int32_t *env_ids, const EbcScene *sc, hipMemcpyKind kind) {
+  int rc;
   DevState &s = h->s;
-  if ((rc = validate_scene(h, sc, env_ids, s.E)) != EBC_OK) return rc;
   const int n = sc->n, N = s.N;
   if (n > s.E) return fail(EBC_ERR_INVALID, "scene.n out of range");
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -542,11 +544,11 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *sc) {
                          s.n_static, s.spx, s.spy, s.sradius, nullptr, s.robot};
   EbcScene no_grid = *sc;
   no_grid.grid = nullptr;
-  if ((rc = upload_scene(h, &no_grid, env_ids, live, false)) != EBC_OK) return rc;
+  if ((rc = upload_scene(h, &no_grid, env_ids, live, false, kind)) != EBC_OK) return rc;
   // ... and reset slot e of the pool (auto-reset source, and the home of env e's occupancy grid)
   const SceneDst slot = {pl.n_humans, pl.px, pl.py, pl.vx, pl.vy, pl.gx, pl.gy, pl.radius, pl.v_pref,
                          pl.type, pl.n_static, pl.spx, pl.spy, pl.sradius, h->pool_grid_alloc, pl.robot};
-  if ((rc = upload_scene(h, sc, env_ids, slot, pl.grid != nullptr)) != EBC_OK) return rc;
+  if ((rc = upload_scene(h, sc, env_ids, slot, pl.grid != nullptr, kind)) != EBC_OK) return rc;
   // per-env scalars: global_time = 0, arrival = 0, done = 0 (env.py:149-151); grid and restart slot
   bool contiguous = true;
   for (int r = 0; r < n && env_ids; ++r)
@@ -589,12 +591,17 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *sc) {
   return EBC_OK;
 }
 
-int ebc_set_scene_pool(void *handle, const EbcScene *sc, int stride) {
+int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *sc) {
   Handle *h;
   int rc = check_handle(handle, &h);
   if (rc) return rc;
+  if ((rc = validate_scene(h, sc, env_ids, h->s.E)) != EBC_OK) return rc;
+  return reset_impl(h, env_ids, sc, hipMemcpyHostToDevice);
+}
+
+static int pool_impl(Handle *h, const EbcScene *sc, int stride, hipMemcpyKind kind) {
+  int rc;
   DevState &s = h->s;
-  if ((rc = validate_scene(h, sc, nullptr, sc ? sc->n : 0)) != EBC_OK) return rc;
   if (stride < 0) return fail(EBC_ERR_INVALID, "stride");
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int P = sc->n, E = s.E;
@@ -606,7 +613,7 @@ int ebc_set_scene_pool(void *handle, const EbcScene *sc, int stride) {
                          pl.gx + E * N, pl.gy + E * N, pl.radius + E * N, pl.v_pref + E * N, pl.type + E * N,
                          pl.n_static + E, pl.spx + E * S, pl.spy + E * S, pl.sradius + E * S,
                          h->pool_grid_alloc + (size_t)E * s.G * 2, pl.robot + (size_t)E * 9};
-  if ((rc = upload_scene(h, sc, nullptr, slot, false)) != EBC_OK) return rc;
+  if ((rc = upload_scene(h, sc, nullptr, slot, false, kind)) != EBC_OK) return rc;
   {
     const size_t first = (size_t)E * N, count = (size_t)P * N;
     hipLaunchKernelGGL(ebc::pool_pref_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, h->stream, h->s, first, count);
@@ -618,6 +625,143 @@ int ebc_set_scene_pool(void *handle, const EbcScene *sc, int stride) {
   for (int e = 0; e < E; ++e) cur[e] = E + e % P;
   HIP_TRY(hipMemcpy(pl.cursor, cur.data(), (size_t)E * sizeof(int), hipMemcpyHostToDevice));
   return EBC_OK;
+}
+
+int ebc_set_scene_pool(void *handle, const EbcScene *sc, int stride) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if ((rc = validate_scene(h, sc, nullptr, sc ? sc->n : 0)) != EBC_OK) return rc;
+  return pool_impl(h, sc, stride, hipMemcpyHostToDevice);
+}
+
+// ---- scenes generated on the device (ebc_scene_gen.h)
+namespace {
+struct GenBatch {  // n generated scenes in device memory, freed with the object
+  std::vector<void *> allocs;
+  EbcScene sc;  // device pointers
+  ~GenBatch() {
+    for (void *ptr : allocs) (void)hipFree(ptr);
+  }
+};
+
+int validate_gen(const Handle *h, const EbcSceneGen *g, int n) {
+  if (!g || g->struct_size != sizeof(EbcSceneGen)) return fail(EBC_ERR_INVALID, "EbcSceneGen.struct_size");
+  if (n <= 0) return fail(EBC_ERR_INVALID, "number of scenes");
+  long total = 0;
+  for (int t = 0; t < 3; ++t) {
+    if (g->count[t] < 0) return fail(EBC_ERR_INVALID, "EbcSceneGen.count");
+    total += g->count[t];
+    if (!g->count[t]) continue;
+    const int r = g->rule[t];
+    if (r != EBC_RULE_CIRCLE_CROSSING && r != EBC_RULE_SQUARE_CROSSING && r != EBC_RULE_SQUARE_CROSSING_OLD)
+      return fail(EBC_ERR_INVALID, "EbcSceneGen.rule");
+    // what the reference itself cannot run (scene_generator.py:449-457 raises for children on the circle; the
+    // old square rule exists for bicycles only, :459-498)
+    if (r == EBC_RULE_CIRCLE_CROSSING && t == EBC_CHILD) return fail(EBC_ERR_INVALID, "circle_crossing is not defined for children");
+    if (r == EBC_RULE_SQUARE_CROSSING_OLD && t != EBC_BICYCLE) return fail(EBC_ERR_INVALID, "square_crossing_old is defined for bicycles only");
+  }
+  if (total > h->s.N) return fail(EBC_ERR_INVALID, "the generated scenes have more humans than max_humans");
+  if (g->num_circles < 0 || g->num_walls < 0) return fail(EBC_ERR_INVALID, "EbcSceneGen.num_circles / num_walls");
+  if (g->num_walls > 0 && (g->min_wall_length < 1 || g->max_wall_length < g->min_wall_length))
+    return fail(EBC_ERR_INVALID, "EbcSceneGen.min_wall_length / max_wall_length");
+  if (!(g->map_resolution > 0) || (int)std::nearbyint(g->map_size_m / g->map_resolution) != h->s.G)
+    return fail(EBC_ERR_INVALID, "EbcSceneGen map size differs from the handle's");
+  if (g->num_circles + g->num_walls > 0 && h->s.S == 0)
+    return fail(EBC_ERR_INVALID, "a map with obstacles needs max_static > 0");
+  return EBC_OK;
+}
+
+int generate_batch(Handle *h, const EbcSceneGen *gen, uint32_t seed0, const uint32_t *seeds, int n, GenBatch &b) {
+  int rc = validate_gen(h, gen, n);
+  if (rc) return rc;
+  const int N = h->s.N, S = h->s.S, G = h->s.G;
+  const size_t nN = (size_t)n * N, nS = (size_t)n * (S ? S : 1);
+  auto get = [&](auto **out, size_t count) -> int {
+    void *ptr = nullptr;
+    HIP_TRY(hipMalloc(&ptr, count * sizeof(**out) + 16));
+    b.allocs.push_back(ptr);
+    *out = reinterpret_cast<std::remove_reference_t<decltype(*out)>>(ptr);
+    return EBC_OK;
+  };
+  ebc::SceneRow d = {};
+  uint32_t *mt = nullptr, *dseeds = nullptr;
+  int *status = nullptr;
+  const bool with_grid = gen->num_circles + gen->num_walls > 0;
+#define G_(f, c) if (rc == EBC_OK) rc = get(&d.f, (c))
+  G_(n_humans, n); G_(px, nN); G_(py, nN); G_(vx, nN); G_(vy, nN); G_(gx, nN); G_(gy, nN); G_(radius, nN); G_(v_pref, nN);
+  G_(type, nN); G_(n_static, n); G_(spx, nS); G_(spy, nS); G_(sradius, nS); G_(robot, (size_t)n * 9);
+  if (with_grid) G_(grid, (size_t)n * G * 2);
+#undef G_
+  if (rc == EBC_OK) rc = get(&mt, (size_t)n * 624);
+  if (rc == EBC_OK) rc = get(&status, 1);
+  if (rc == EBC_OK && seeds) rc = get(&dseeds, n);
+  if (rc) return rc;
+  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), h->stream));
+  if (seeds) HIP_TRY(hipMemcpyAsync(dseeds, seeds, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(ebc::scene_gen_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, h->stream, *gen, (const uint32_t *)dseeds,
+                     seed0, n, N, S, G, d, mt, status);
+  HIP_TRY(hipGetLastError());
+  int st = 0;
+  HIP_TRY(hipMemcpyAsync(&st, status, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (st & EBC_GEN_STATIC_OVERFLOW) return fail(EBC_ERR_INVALID, "a generated map has more observation rows than max_static");
+  EbcScene &sc = b.sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.struct_size = sizeof(EbcScene);
+  sc.n = n;
+  sc.n_humans = d.n_humans;
+  sc.px = d.px; sc.py = d.py; sc.vx = d.vx; sc.vy = d.vy; sc.gx = d.gx; sc.gy = d.gy; sc.radius = d.radius; sc.v_pref = d.v_pref;
+  sc.type = d.type;
+  sc.n_static = d.n_static;
+  sc.spx = d.spx; sc.spy = d.spy; sc.sradius = d.sradius;
+  sc.grid = d.grid;
+  sc.robot = d.robot;
+  return EBC_OK;
+}
+}  // namespace
+
+int ebc_generate_scenes(void *handle, const EbcSceneGen *gen, uint32_t seed0, const uint32_t *seeds, int n, EbcSceneOut *out) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if (!out || out->struct_size != sizeof(EbcSceneOut)) return fail(EBC_ERR_INVALID, "EbcSceneOut.struct_size");
+  GenBatch b;
+  if ((rc = generate_batch(h, gen, seed0, seeds, n, b)) != EBC_OK) return rc;
+  const hipMemcpyKind kind = out->location == EBC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  const size_t N = h->s.N, S = h->s.S ? h->s.S : 1, G = h->s.G;
+  const EbcScene &sc = b.sc;
+#define OUT_(f, bytes) if (out->f && sc.f) HIP_TRY(hipMemcpy(out->f, sc.f, (size_t)n * (bytes), kind))
+  OUT_(n_humans, sizeof(int)); OUT_(px, N * 8); OUT_(py, N * 8); OUT_(vx, N * 8); OUT_(vy, N * 8); OUT_(gx, N * 8); OUT_(gy, N * 8);
+  OUT_(radius, N * 8); OUT_(v_pref, N * 8); OUT_(type, N); OUT_(n_static, sizeof(int)); OUT_(spx, S * 8); OUT_(spy, S * 8);
+  OUT_(sradius, S * 8); OUT_(robot, 72); OUT_(grid, G * 16);
+#undef OUT_
+  if (out->grid && !sc.grid) {  // free maps
+    if (out->location == EBC_DEVICE) HIP_TRY(hipMemset(out->grid, 0, (size_t)n * G * 16));
+    else memset(out->grid, 0, (size_t)n * G * 16);
+  }
+  return EBC_OK;
+}
+
+int ebc_generate_reset(void *handle, const EbcSceneGen *gen, uint32_t seed0, const uint32_t *seeds, int first, int n) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if (first < 0 || n <= 0 || (long)first + n > h->s.E) return fail(EBC_ERR_INVALID, "env range");
+  GenBatch b;
+  if ((rc = generate_batch(h, gen, seed0, seeds, n, b)) != EBC_OK) return rc;
+  std::vector<int32_t> ids(n);
+  for (int r = 0; r < n; ++r) ids[r] = first + r;
+  return reset_impl(h, ids.data(), &b.sc, hipMemcpyDeviceToDevice);
+}
+
+int ebc_generate_pool(void *handle, const EbcSceneGen *gen, uint32_t seed0, const uint32_t *seeds, int n, int stride) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  GenBatch b;
+  if ((rc = generate_batch(h, gen, seed0, seeds, n, b)) != EBC_OK) return rc;
+  return pool_impl(h, &b.sc, stride, hipMemcpyDeviceToDevice);
 }
 
 int ebc_set_human_actions(void *handle, int location, const double *act) {

@@ -55,6 +55,29 @@ class EbcScene(C.Structure):
     ]
 
 
+class EbcSceneGen(C.Structure):
+    """include/ebcsim.h: the keys SceneGenerator.__init__ reads, phase resolved (scene.SceneConfig.gen_struct)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("randomize_attributes", C.c_int32),
+        ("count", C.c_int32 * 3),
+        ("rule", C.c_int32 * 3),
+    ] + [(k, C.c_double * 3) for k in ("radius", "v_pref", "radius_min", "radius_max", "v_pref_min", "v_pref_max")] + [
+        (k, C.c_double) for k in ("square_width", "circle_radius", "discomfort_dist", "robot_radius", "robot_v_pref",
+                                  "map_resolution", "map_size_m")
+    ] + [(k, C.c_int32) for k in ("min_wall_length", "max_wall_length", "num_circles", "num_walls")]
+
+
+class EbcSceneOut(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("location", C.c_int32), ("n_humans", _pd)] + [
+        (k, _pd) for k in ("px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
+                           "n_static", "spx", "spy", "sradius", "grid", "robot")
+    ]
+
+
+RULE_CIRCLE_CROSSING, RULE_SQUARE_CROSSING, RULE_SQUARE_CROSSING_OLD = 0, 1, 2
+
+
 class EbcStepArgs(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32),

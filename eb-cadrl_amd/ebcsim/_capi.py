@@ -30,6 +30,9 @@ SYMBOLS = {
     "ebc_step_k": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_get_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_row_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ebc_generate_scenes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]),
+    "ebc_generate_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int]),
+    "ebc_generate_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_int]),
     "ebc_il_targets": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double,
                                  C.c_void_p, C.c_void_p]),
     "ebc_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

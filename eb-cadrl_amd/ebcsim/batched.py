@@ -99,6 +99,57 @@ class BatchedEnv:
         _capi.check(self._L.ebc_set_scene_pool(self._h, C.addressof(sc), int(self.E if stride is None else stride)))
         self._note_rows(scene)
 
+    # ------------------------------------------------------------------ scenes generated on the device
+    # (SceneGenerator.generate_random_scene, scene_generator.py:330-378; gen = scene.gen_struct(cfg, phase))
+    @staticmethod
+    def _seeds(seeds, n):
+        """(seed0, pointer, keep-alive) for `seeds` = first seed (int: seed0 + i) or an array of n seeds."""
+        if np.isscalar(seeds):
+            return int(seeds) & 0xFFFFFFFF, None, None
+        a = np.ascontiguousarray(seeds, dtype=np.uint32)
+        if a.shape != (n,):
+            raise ValueError("seeds must be one int or %d of them" % n)
+        return 0, a.ctypes.data, a
+
+    def _note_generated(self, gen):
+        humans = sum(gen.count)
+        self.ragged = bool(getattr(self, "ragged", False) or humans < self.N or gen.num_walls > 0
+                           or gen.num_circles < self.S)
+
+    def generate_scenes(self, gen, seeds, n):
+        """n generated scenes copied back as a scene.SceneBatch (what generate_scene + from_scenes build on the host)."""
+        from .scene import SceneBatch
+        seed0, ptr, keep = self._seeds(seeds, n)
+        N, S, G = self.N, max(self.S, 1), self.G
+        f = lambda *sh: np.zeros(sh, dtype=np.float64)  # noqa: E731
+        b = SceneBatch(n, self.N, self.S, np.zeros(n, np.int32), f(n, N), f(n, N), f(n, N), f(n, N), f(n, N), f(n, N),
+                       f(n, N), f(n, N), np.zeros((n, N), np.uint8), np.zeros(n, np.int32), f(n, S), f(n, S), f(n, S),
+                       np.zeros((n, G, 2), np.uint64), f(n, 9))
+        out = _abi.EbcSceneOut()
+        out.struct_size = C.sizeof(out)
+        out.location = _abi.HOST
+        for k in ("n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type", "n_static", "spx", "spy",
+                  "sradius", "grid", "robot"):
+            setattr(out, k, getattr(b, k).ctypes.data)
+        _capi.check(self._L.ebc_generate_scenes(self._h, C.addressof(gen), seed0, ptr, int(n), C.addressof(out)))
+        if gen.num_circles + gen.num_walls == 0:
+            b.grid = None
+        return b
+
+    def generate_reset(self, gen, seeds, first=0, n=None):
+        """env.reset of envs first..first+n-1 from scenes generated on the device (only the seeds cross PCIe)."""
+        n = self.E - first if n is None else n
+        seed0, ptr, keep = self._seeds(seeds, n)
+        _capi.check(self._L.ebc_generate_reset(self._h, C.addressof(gen), seed0, ptr, int(first), int(n)))
+        self._note_generated(gen)
+
+    def generate_pool(self, gen, seeds, n, stride=None):
+        """set_scene_pool with n scenes generated on the device."""
+        seed0, ptr, keep = self._seeds(seeds, n)
+        _capi.check(self._L.ebc_generate_pool(self._h, C.addressof(gen), seed0, ptr, int(n),
+                                              int(self.E if stride is None else stride)))
+        self._note_generated(gen)
+
     # ------------------------------------------------------------------ host calls
     def set_human_actions(self, act):
         a = np.ascontiguousarray(act, dtype=np.float64).reshape(self.E, self.N, 2)

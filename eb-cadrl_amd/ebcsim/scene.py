@@ -102,6 +102,50 @@ class SceneConfig:
         return s
 
 
+def max_static_rows(cfg: "SceneConfig") -> int:
+    """Upper bound on the observation rows of a generated map (static_rows): one per circle, and a wall of length
+    L (width 1) yields circles of radius sqrt(2)/2 every sqrt(2) along it: fewer than L of them."""
+    return (cfg.num_circles or 0) + (cfg.num_walls or 0) * max(int(cfg.max_wall_length), 1)
+
+
+_RULES = {"circle_crossing": _abi.RULE_CIRCLE_CROSSING, "square_crossing": _abi.RULE_SQUARE_CROSSING,
+          "square_crossing_old": _abi.RULE_SQUARE_CROSSING_OLD}
+
+
+def gen_struct(cfg: SceneConfig, phase: str = "test", multiagent_training: bool = True) -> "_abi.EbcSceneGen":
+    """The EbcSceneGen of include/ebcsim.h for one phase: what `generate_scene(cfg, seed, phase)` would place,
+    for the device generator (ebc_generate_*).  Rules the reference cannot run raise here, as in `_Gen.group`."""
+    import ctypes as C
+    g = _abi.EbcSceneGen()
+    g.struct_size = C.sizeof(g)
+    test = phase == "test"
+    many = test or multiagent_training
+    rules = ((cfg.test_sim_adult, cfg.test_sim_bicycle, cfg.test_sim_children) if test else
+             (cfg.train_val_sim_adult, cfg.train_val_sim_bicycle, cfg.train_val_sim_children))
+    counts = (cfg.adult_num, cfg.bicycle_num, cfg.children_num)
+    g.randomize_attributes = int(bool(cfg.randomize_attributes))
+    for t, (spec, rule, count) in enumerate(zip((cfg.adults, cfg.bicycles, cfg.children), rules, counts)):
+        n = count if many else 1
+        g.count[t] = n
+        if n:
+            if rule not in _RULES or (rule == "circle_crossing" and t == _abi.CHILD) or (
+                    rule == "square_crossing_old" and t != _abi.BICYCLE):
+                raise ValueError("unsupported crossing rule %r for type %d" % (rule, t))
+            g.rule[t] = _RULES[rule]
+        for key in ("radius", "v_pref", "radius_min", "radius_max", "v_pref_min", "v_pref_max"):
+            v = getattr(spec, key)
+            if v is None and n and (cfg.randomize_attributes) == key.endswith(("_min", "_max")):
+                raise ValueError("[%s] %s missing" % (("adults", "bicycles", "children")[t], key))
+            getattr(g, key)[t] = 0.0 if v is None else float(v)
+    g.square_width, g.circle_radius = cfg.square_width, cfg.circle_radius
+    g.discomfort_dist = cfg.discomfort_dist
+    g.robot_radius, g.robot_v_pref = cfg.robot.radius, cfg.robot.v_pref
+    g.map_resolution, g.map_size_m = cfg.map_resolution, cfg.map_size_m
+    g.min_wall_length, g.max_wall_length = cfg.min_wall_length, cfg.max_wall_length
+    g.num_circles, g.num_walls = cfg.num_circles or 0, cfg.num_walls or 0
+    return g
+
+
 @dataclass
 class Human:
     px: float

@@ -227,6 +227,58 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *scene);
  * ebc_reset scenes (P = E, stride 0).  Does not touch the running episodes. */
 int ebc_set_scene_pool(void *handle, const EbcScene *pool, int stride);
 
+/* ---- SceneGenerator.generate_random_scene on the device (simulator/scene/scene_generator.py:330-378) ----
+ * The keys SceneGenerator.__init__ reads (:20-72) and the per-type agent sections (agents/agent.py:16-35), with
+ * the phase already resolved by the caller: count[t] / rule[t] are the number of humans of AgentType t and its
+ * crossing rule for THIS phase (test_sim_* or train_val_sim_*; 1 human per type when neither `test` nor
+ * multiagent_training, :343-355). */
+enum EbcCrossingRule {
+  EBC_RULE_CIRCLE_CROSSING = 0,     /* scene_generator.py:593-648 (adults, bicycles) */
+  EBC_RULE_SQUARE_CROSSING = 1,     /* :650-712 */
+  EBC_RULE_SQUARE_CROSSING_OLD = 2  /* :714-761 (bicycles only) */
+};
+#define EBC_GEN_STATIC_OVERFLOW 1 /* a generated map has more observation rows than max_static */
+
+typedef struct EbcSceneGen {
+  uint32_t struct_size;
+  int32_t randomize_attributes;      /* [env] randomize_attributes */
+  int32_t count[3];                  /* adults, bicycles, children */
+  int32_t rule[3];                   /* EbcCrossingRule per type */
+  double radius[3], v_pref[3];       /* fixed attributes ([adults] / [bicycles] / [children]) */
+  double radius_min[3], radius_max[3], v_pref_min[3], v_pref_max[3]; /* sample_random_attributes, agent.py:48-56 */
+  double square_width, circle_radius; /* [sim] */
+  double discomfort_dist;            /* [reward] discomfort_dist (the rejection tests' margin) */
+  double robot_radius, robot_v_pref; /* [robot] */
+  double map_resolution, map_size_m; /* [map] */
+  int32_t min_wall_length, max_wall_length, num_circles, num_walls;
+} EbcSceneGen;
+
+/* Arrays a generated batch is copied out to (ebc_generate_scenes): an EbcScene's, writable. */
+typedef struct EbcSceneOut {
+  uint32_t struct_size;
+  int32_t location;          /* EBC_HOST or EBC_DEVICE, of every pointer below */
+  int32_t *n_humans;
+  double *px, *py, *vx, *vy, *gx, *gy, *radius, *v_pref;
+  uint8_t *type;
+  int32_t *n_static;         /* NULL allowed when max_static == 0 */
+  double *spx, *spy, *sradius;
+  uint64_t *grid;            /* [n][G][2] or NULL */
+  double *robot;
+} EbcSceneOut;
+
+/* n scenes generated on the device, one per seed: scene i is what the reference's generate_random_scene draws after
+ * np.random.seed(seeds[i]) (seeds NULL: seed0 + i; env.reset seeds with counter_offset[phase] + case,
+ * simulator/env.py:153-169) — numpy's legacy MT19937 stream, draw for draw, so every value is the reference's bit
+ * for bit, except the cos / sin of circle_crossing (<= 1 ulp: numpy's own results there depend on the CPU).
+ * Shapes follow the handle (max_humans, max_static, grid width); sum(count) must fit max_humans; a map with more
+ * observation rows than max_static is EBC_ERR_INVALID.
+ *   ebc_generate_scenes: copy the batch out (tests, inspection).
+ *   ebc_generate_reset:  env.reset of envs first..first+n-1 from it, nothing crossing PCIe but the seeds.
+ *   ebc_generate_pool:   install it as the EBC_FLAG_AUTO_RESET pool (as ebc_set_scene_pool, P = n). */
+int ebc_generate_scenes(void *handle, const EbcSceneGen *gen, uint32_t seed0, const uint32_t *seeds, int n, EbcSceneOut *out);
+int ebc_generate_reset(void *handle, const EbcSceneGen *gen, uint32_t seed0, const uint32_t *seeds, int first, int n);
+int ebc_generate_pool(void *handle, const EbcSceneGen *gen, uint32_t seed0, const uint32_t *seeds, int n, int stride);
+
 /* Humans moved by the host (BASELINE config 2): act[E][N][2]. */
 int ebc_set_human_actions(void *handle, int location, const double *act);
 

@@ -36,14 +36,15 @@ def test_header_symbols_exported(lib):
 
 def test_struct_sizes_match_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n",'
                    'sizeof(EbcParams),sizeof(EbcScene),sizeof(EbcStepArgs),sizeof(EbcLookaheadArgs),'
-                   'sizeof(EbcStateView),sizeof(EbcStepKArgs));return 0;}\n' % HEADER)
+                   'sizeof(EbcStateView),sizeof(EbcStepKArgs),sizeof(EbcSceneGen),sizeof(EbcSceneOut));return 0;}\n' % HEADER)
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-o", str(exe), str(src)])
     sizes = list(map(int, subprocess.check_output([str(exe)]).split()))
     assert sizes == [C.sizeof(_abi.EbcParams), C.sizeof(_abi.EbcScene), C.sizeof(_abi.EbcStepArgs),
-                     C.sizeof(_abi.EbcLookaheadArgs), C.sizeof(_abi.EbcStateView), C.sizeof(_abi.EbcStepKArgs)]
+                     C.sizeof(_abi.EbcLookaheadArgs), C.sizeof(_abi.EbcStateView), C.sizeof(_abi.EbcStepKArgs),
+                     C.sizeof(_abi.EbcSceneGen), C.sizeof(_abi.EbcSceneOut)]
 
 
 def test_params_default_matches_bindings(lib):

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--gamma", type=float, default=0.9)
     ap.add_argument("--policy", default="sarl", choices=["sarl", "orca"])
     ap.add_argument("--safety-space", type=float, default=0.15)
+    ap.add_argument("--device-scenes", action="store_true",
+                    help="generate the test scenes on the device (ebc_generate_reset) instead of on the host")
     args = ap.parse_args()
     import torch
     from ebcsim import _abi, actions as ebc_actions, config as ebc_config, scene as ebc_scene
@@ -43,14 +45,22 @@ def main():
     sc = ebc_scene.SceneConfig.from_config(cfg)
     t0 = time.perf_counter()
     seeds = [ebc_scene.COUNTER_OFFSET["test"] + args.first_case + c for c in range(args.cases)]
-    batch = ebc_scene.SceneBatch.from_scenes([ebc_scene.generate_scene(sc, s, "test") for s in seeds])
+    if args.device_scenes:
+        gen = ebc_scene.gen_struct(sc, "test")
+        env = BatchedEnv(params, args.cases, sum(gen.count), ebc_scene.max_static_rows(sc))
+        env.generate_reset(gen, seeds[0])
+        env.synchronize()
+        v_pref = sc.robot.v_pref
+    else:
+        batch = ebc_scene.SceneBatch.from_scenes([ebc_scene.generate_scene(sc, s, "test") for s in seeds])
+        env = BatchedEnv(params, args.cases, batch.N, batch.S)
+        env.reset(batch)
+        v_pref = float(batch.robot[0, 7])
     t1 = time.perf_counter()
-    env = BatchedEnv(params, args.cases, batch.N, batch.S)
-    env.reset(batch)
     env.use_torch_stream()
     if args.policy == "sarl":
         net = SarlValueNet.load(args.weights, device="cuda:0")
-        policy = DeviceSarlPolicy(net, ebc_actions.build_action_space(float(batch.robot[0, 7])), args.gamma)
+        policy = DeviceSarlPolicy(net, ebc_actions.build_action_space(v_pref), args.gamma)
         decide, hp = (lambda e: policy.decide(e)[0]), _abi.HUMAN_CACHED
     else:
         act = torch.zeros((args.cases, 2), dtype=torch.float64, device="cuda:0")
@@ -70,7 +80,7 @@ def main():
               m["collision_rate_obstacle"], m["timeout"], m["avg_nav_time"], m["total_reward:"]))
     print("Frequency of being in danger: %.2f and average min separate distance in danger: %.2f" % (
         m["Frequency of being in danger"] or 0.0, m["average min separate distance in danger"]))
-    print(json.dumps({"cases": args.cases, "policy": args.policy, "scene_generation_s": t1 - t0, "episodes_s": t3 - t2,
+    print(json.dumps({"cases": args.cases, "policy": args.policy, "scenes": "device" if args.device_scenes else "host", "scene_generation_s": t1 - t0, "episodes_s": t3 - t2,
                       "episodes_per_s": args.cases / (t3 - t2),
                       "metrics": {k: v for k, v in m.items() if not isinstance(v, list)}}))
 

@@ -41,9 +41,17 @@ def main():
     outs = env.alloc_step_outputs(("reward", "done", "info", "obs_rotated"))
     fl = _abi.FLAG_AUTO_RESET
     for hp in (_abi.HUMAN_LINEAR, _abi.HUMAN_ORCA):
-        for _ in range(50):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for i in range(60):
+            if i == 10:
+                ev[0].record()
             env.step_device(outs, human_policy=hp, robot_policy=_abi.ROBOT_LINEAR, flags=fl)
+        ev[1].record()
         torch.cuda.synchronize()
+        # the launch-to-launch period of THIS build, to set beside the last wave's end below: the difference is
+        # what the launch spends before its first wave and after its last one (dispatch, end-of-kernel write-back)
+        print("%s: %.2f us per step over 50 back-to-back launches (events)" % (
+            "linear humans" if hp == _abi.HUMAN_LINEAR else "ORCA humans", ev[0].elapsed_time(ev[1]) * 1e3 / 50))
     t = buf.cpu().numpy().astype(np.uint64)
     launch0 = None
     for tag in (2, 3, 1):
