@@ -61,6 +61,13 @@ def build_batch(workload, envs, rank):
     return params, ebc_scene.SceneBatch.from_scenes(scenes)
 
 
+def scene_config(workload):
+    from ebcsim import scene as ebc_scene
+    cfg = configparser.RawConfigParser()
+    cfg.read(os.path.join(PKG, "configs", WORKLOADS[workload][0]))
+    return ebc_scene.SceneConfig.from_config(cfg)
+
+
 def host_cores(cap=16):
     """Threads for the all-cores CPU baseline: this process's CPU share — its affinity mask, cut
     to the cgroup quota when one is set, and to `cap` (the CPU share of a one-GPU box: a mask of
@@ -201,7 +208,7 @@ def ebc_scene_slice_range(batch, lo, hi):
             "n_static", "spx", "spy", "sradius", "grid", "robot")])
 
 
-def also_kernels(env, batch, dev):
+def also_kernels(env, batch, dev, cfg_s=None):
     """The two other kernels of the path with a roofline of their own, measured live (HIP events on
     the launch stream; inputs resident in HBM): the 81-action look-ahead sweep whose rotated rows
     are the one HBM-bound output of the path, and the value network's first block, which consumes
@@ -257,6 +264,33 @@ def also_kernels(env, batch, dev):
         del ko
     except Exception as e:
         out.append({"kernel": "ebc_step_k", "error": repr(e)})
+    try:
+        # env.reset of the whole batch from scenes generated on the device (scene_gen_kernel: numpy's MT19937 stream
+        # and the reference's rejection loops, one lane per scene) beside the host generator doing the same scenes
+        import time as _t
+        from ebcsim import scene as ebc_scene
+        if cfg_s is not None:
+            from ebcsim.batched import BatchedEnv as _BE
+            gen = ebc_scene.gen_struct(cfg_s, "test")
+            genv = _BE(env.params, env.E, sum(gen.count), ebc_scene.max_static_rows(cfg_s), device=dev.index or 0)
+            genv.generate_reset(gen, 1000)  # warm: first launch, allocations
+            t0 = _t.perf_counter()
+            for r in range(3):
+                genv.generate_reset(gen, 1000 + r * env.E)
+            genv.synchronize()
+            dev_ms = (_t.perf_counter() - t0) / 3 * 1e3
+            n_host = min(env.E, 256)
+            t0 = _t.perf_counter()
+            for s_ in range(n_host):
+                ebc_scene.generate_scene(cfg_s, 1000 + s_, "test")
+            host_ms = (_t.perf_counter() - t0) * 1e3 * env.E / n_host
+            out.append({"kernel": "scene_gen_kernel: env.reset of %d envs from scenes generated on the device "
+                                  "(ebc_generate_reset, seeds only over PCIe)" % env.E,
+                        "call_ms": dev_ms, "scenes_per_s": env.E / (dev_ms * 1e-3),
+                        "host_generator_ms_same_scenes": host_ms, "host_sample": "%d scenes, scaled" % n_host})
+            del genv
+    except Exception as e:
+        out.append({"kernel": "scene_gen_kernel", "error": repr(e)})
     try:
         # The same batch as TWO independent sub-batches, each a handle on its own HIP stream (scenes are independent:
         # the split is exact): launches of the two overlap, one's tail under the other's head.  Reported beside the
@@ -461,7 +495,7 @@ def main():
 
     also = None
     if rank == 0 and world == 1 and not args.no_also and args.human_policy == "orca":
-        also = also_kernels(env, batch, dev)
+        also = also_kernels(env, batch, dev, scene_config(args.workload))
 
     from ebcsim import shard
     elapsed_max, total_humans = shard.job_rate(elapsed, float(batch.n_humans.sum()),

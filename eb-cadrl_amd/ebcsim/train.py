@@ -396,7 +396,7 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
                  batch_size=100, capacity=100000, epsilon_start=0.5, epsilon_end=0.1, epsilon_decay=4000,
                  target_update_interval=50, optimizer_algorithm="sgd", generator=None, log=None,
                  output_dir=None, checkpoint_interval=0, evaluation_interval=0, val_env=None, val_scenes=None,
-                 rank=0):
+                 rank=0, scene_gen=None, scene_seed0=2000, scene_pool_factor=4, scene_pool_steps=None):
     """The schedule of rl/train.py:99-260 on one rank's env slice (every rank calls it; gradients are
     averaged over ranks inside the trainer): imitation learning with the robot on ORCA
     (`il_steps` steps of every env, then `il_epochs` passes over the memory), then `train_iterations`
@@ -409,7 +409,13 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
     (train.py:113-116) — and `rl_model_<round>.pth` every `checkpoint_interval` rounds and at the end
     (train.py:146-150, :262-270); written by `rank` 0 only.  evaluation_interval: every so many rounds the
     greedy policy runs `val_scenes` (a SceneBatch) on `val_env` once through (train.py:222-236, `evaluate`);
-    the metrics go to hist["val"]."""
+    the metrics go to hist["val"].
+    scene_gen: an EbcSceneGen (scene.gen_struct(cfg, "train")): the episodes then run on scenes generated on the
+    device from consecutive seeds starting at `scene_seed0` (the reference: seed = 2000 + the number of train
+    episodes so far, simulator/env.py:153-169; here every env draws from its own run of that sequence — give each
+    rank its own `scene_seed0`): the envs are reset from the first E seeds, the auto-reset pool holds the next
+    `scene_pool_factor` x E and is regenerated from fresh seeds every `scene_pool_steps` env steps (default: before
+    an env can have walked through its share), with nothing but the seed crossing PCIe."""
     import os
     from .sarl import DeviceSarlPolicy
     dev = next(model.parameters()).device
@@ -440,8 +446,32 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
             log("imitation learning: weights loaded from %s" % il_file)
     broadcast_parameters_(model, 0)
     red_dev = dev if (dev.type == "cuda" and _multi_rank() and dist.get_backend() == "nccl") else None
+    next_seed, pool_age = [int(scene_seed0)], [0]
+    if scene_pool_steps is None:  # an episode is at least a few steps long: a pool of f scenes per env lasts longer than 4 f steps
+        scene_pool_steps = 4 * scene_pool_factor
+
+    def fresh_pool(steps_done=0):
+        if scene_gen is None:
+            return
+        pool_age[0] += steps_done
+        if steps_done and pool_age[0] < scene_pool_steps:
+            return
+        P = scene_pool_factor * env.E
+        env.generate_pool(scene_gen, next_seed[0], P)
+        next_seed[0] += P
+        pool_age[0] = 0
+        hist["scene_pools"] = hist.get("scene_pools", 0) + 1
+    if scene_gen is not None:
+        env.generate_reset(scene_gen, next_seed[0])
+        next_seed[0] += env.E
+        fresh_pool()
     if il_steps > 0:
+        if scene_gen is not None and il_steps > scene_pool_steps:  # a pool that lasts the whole stage
+            P = min(-(-il_steps // 4), 16) * env.E  # capped: a long stage walks its scenes again
+            env.generate_pool(scene_gen, next_seed[0], P)
+            next_seed[0] += P
         hist["il_stored"], hist["il_episodes"] = collect_il(env, memory, il_steps, gamma, il_safety_space)
+        fresh_pool(scene_pool_steps)
         if il_epochs > 0 and all_ranks(len(memory) > 0, red_dev):  # every rank's shard has data, or nobody trains
             hist["il_loss"] = trainer.optimize_epoch(il_epochs, generator)
         if il_file:
@@ -466,6 +496,7 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
         eps = epsilon_start + (epsilon_end - epsilon_start) / epsilon_decay * it if it < epsilon_decay else epsilon_end
         mean_r = collect(env, policy, target.as_value_net(), memory, steps_per_iteration, gamma, epsilon=eps,
                          generator=generator, store=store)
+        fresh_pool(steps_per_iteration)
         # ranks fill their shards at different times (an episode reaches the memory when it ends): the
         # optimizer steps all-reduce gradients, so a round trains on every rank or on none
         loss = trainer.optimize_batch(train_batches, generator) if all_ranks(len(memory) > 0, red_dev) else float("nan")

@@ -231,6 +231,40 @@ def test_run_training_checkpoints_and_validation(tmp_path):
     assert h2["il_loaded"] and h2["il_stored"] == 0
 
 
+@pytest.mark.gpu
+def test_run_training_on_device_generated_scenes():
+    """The schedule with `scene_gen`: every episode on a scene generated on the device from the train seeds
+    (simulator/env.py:153-169: 2000 + episode number), the pool refreshed from fresh seeds between rounds."""
+    import configparser
+    import json
+    from helpers import load, params_of
+    from ebcsim import scene as ebc_scene
+    from ebcsim.batched import BatchedEnv
+    from ebcsim.train import SarlModule, run_training
+    z = load("scenes")
+    meta = json.loads(str(z["meta_0"]))  # env_adults_5: circle crossing, free map
+    cfg = configparser.RawConfigParser()
+    cfg.read_string(meta["config_text"])
+    sc = ebc_scene.SceneConfig.from_config(cfg)
+    gen = ebc_scene.gen_struct(sc, "train")
+    zz = load("sarl_a5_baseline")
+    E = 32
+    env = BatchedEnv(params_of(zz), E, 5, 0)
+    env.use_torch_stream()
+    model = SarlModule(**DIMS).to("cuda:0")
+    hist = run_training(env, model, zz["action_space"], 0.9, il_steps=60, il_epochs=1, train_iterations=3,
+                        steps_per_iteration=8, train_batches=2, capacity=20000, epsilon_decay=2, scene_gen=gen,
+                        scene_seed0=2000, scene_pool_factor=2)
+    assert hist["il_episodes"] > 0 and hist["scene_pools"] >= 3
+    # every env now runs a scene of the train sequence: its goals are those of one of the seeds drawn so far
+    st = env.get_state()
+    drawn = E + 2 * E + 15 * E + hist["scene_pools"] * 2 * E
+    ref = env.generate_scenes(gen, 2000, drawn)
+    goals = {(float(a), float(b)) for a, b in zip(ref.gx[:, 0], ref.gy[:, 0])}
+    assert all((float(st["gx"][e, 0]), float(st["gy"][e, 0])) in goals for e in range(E))
+    assert len({float(st["gx"][e, 0]) for e in range(E)}) > E // 2  # and not all the same scene
+
+
 def test_episode_store_keeps_successes_and_collisions_only():
     """explorer.py:82-92: pairs reach the memory when their episode ends, and only for ReachGoal or a
     collision; a timeout's pairs are dropped; an unfinished episode keeps waiting."""
