@@ -64,7 +64,11 @@ struct Handle {
 template <typename Tp>
 int dev_alloc(Handle *h, Tp **out, size_t count) {
   void *ptr = nullptr;
-  HIP_TRY(hipMalloc(&ptr, count * sizeof(Tp) + 16));
+  static const char *uncached = getenv("EBCSIM_UNCACHED_STATE");  // experiment: state the L2s do not hold
+  if (uncached && uncached[0] == '1')
+    HIP_TRY(hipExtMallocWithFlags(&ptr, count * sizeof(Tp) + 16, hipDeviceMallocUncached));
+  else
+    HIP_TRY(hipMalloc(&ptr, count * sizeof(Tp) + 16));
   HIP_TRY(hipMemset(ptr, 0, count * sizeof(Tp) + 16));
   h->allocs.push_back(ptr);
   *out = (Tp *)ptr;
