@@ -48,12 +48,24 @@ __device__ __forceinline__ Frag2 split8(const float (&v)[8]) {
 //     pair's mean-state term of attention layer 0, cat([h1, g]) without the concatenation);
 //   final_w [O], final_b: a third layer with one output, y [M] = final_w . relu(out) + final_b,
 //     worked out from the accumulators instead of storing out [M][O].
+//   partial [ceil(M / 32)][3][O]: per 32-row tile, the weighted sums of its rows over each of the (at most three,
+//     seg_rows >= 16) consecutive row groups of seg_rows rows it touches — sum_r row_weight[r] * y[r][:] (row_weight
+//     NULL: 1) — so that a per-group mean (sarl.py:56-58) or attention-weighted sum (sarl.py:73-76) is the sum of
+//     two or three of these (pair_combine_kernel) instead of a second pass over y; store_y == 0: y itself is not
+//     written at all.  The sums are kept in float64 (products of two float32 are exact there, 18 of them add up
+//     with 2^-53 relative error): whatever rows of a pair share a tile, whichever lanes hold them, the float32 the
+//     combine step rounds to is the same — identical pairs at different places of the batch get identical results,
+//     as with a serial row loop.
 struct MlpExtra {
   const float *row_bias;
   int group_rows, H;
   const float *final_w;
   float final_b;
+  const float *row_weight;
+  double *partial;
+  int seg_rows, store_y;
 };
+#define EBC_VN_SEGS 3
 
 // Packed layer: A fragments [out tile][in tile][k-step 0/1][hi, lo][lane][8 bf16] and the bias in
 // accumulator order [out tile][lane half][16].
@@ -391,6 +403,28 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
     const LdsF4 yt = (LdsF4)(reinterpret_cast<unsigned char *>(wbuf) + (size_t)wave * 32 * EBC_VN_XROW);
     const int m0 = (blockIdx.x * NW + wave) * 32;
     const int piece = lane & 7, rsub = lane >> 3;
+    // The row-group sums (MlpExtra.partial).  Lane (col, half) owns unit `col` of the parked tile and walks rows
+    // 16 half .. 16 half + 15 down its column: 16 rows meet at most two groups (seg_rows >= 16), so two float64
+    // accumulators and the index of the first row of the second group do; the rows' weights wait, as float64, in the
+    // 16 spare bytes each 144-byte tile row has.  One exchange between the halves per tile and group finishes it.
+    const bool reduce = ex.partial != nullptr;
+    typedef float __attribute__((address_space(3))) *LdsF;
+    typedef double __attribute__((address_space(3))) *LdsD;
+    const LdsF ytf = (LdsF)yt;
+    const LdsD ytd = (LdsD)yt;
+    int bnd = 16, seg_lo = 0;
+    if (reduce) {
+      if (lane < 32) {
+        const int row = m0 + lane;
+        ytd[(lane * EBC_VN_XROW + 128) / 8] = row < M ? (ex.row_weight ? (double)ex.row_weight[row] : 1.0) : 0.0;
+      }
+      const int row0 = m0 + 16 * half, s0 = row0 / ex.seg_rows;
+      seg_lo = s0 - m0 / ex.seg_rows;
+      const int next = (s0 + 1) * ex.seg_rows - row0;  // rows of this half before the next group starts
+      bnd = next < 16 ? next : 16;
+      __builtin_amdgcn_wave_barrier();
+    }
+    const bool store = ex.store_y != 0 || !reduce;
 #pragma unroll
     for (int t = 0; t < TO; ++t) {
 #pragma unroll
@@ -401,11 +435,30 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
         yt[(col * EBC_VN_XROW + (8 * g + 4 * half) * 4) / 16] = v;  // units 8 g + 4 half .. + 3 of row `col`
       }
       __builtin_amdgcn_wave_barrier();
+      if (store) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int r = rsub + 8 * q, unit = t * 32 + 4 * piece;
-        const vn_f32x4 v = yt[(r * EBC_VN_XROW + piece * 16) / 16];
-        if (m0 + r < M && unit + 3 < O) *reinterpret_cast<vn_f32x4 *>(Y + (size_t)(m0 + r) * O + unit) = v;
+        for (int q = 0; q < 4; ++q) {
+          const int r = rsub + 8 * q, unit = t * 32 + 4 * piece;
+          const vn_f32x4 v = yt[(r * EBC_VN_XROW + piece * 16) / 16];
+          if (m0 + r < M && unit + 3 < O) *reinterpret_cast<vn_f32x4 *>(Y + (size_t)(m0 + r) * O + unit) = v;
+        }
+      }
+      if (reduce) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = 16 * half + i;
+          const double pv = ytd[(r * EBC_VN_XROW + 128) / 8] * (double)ytf[(r * EBC_VN_XROW) / 4 + col];
+          a0 += i < bnd ? pv : 0.0;
+          a1 += i < bnd ? 0.0 : pv;
+        }
+        const int unit = t * 32 + col;
+#pragma unroll
+        for (int sg = 0; sg < EBC_VN_SEGS; ++sg) {
+          double c = (seg_lo == sg ? a0 : 0.0) + (seg_lo + 1 == sg ? a1 : 0.0);
+          c += __shfl_xor(c, 32, 64);
+          if (half == 0 && unit < O) ex.partial[((size_t)(m0 >> 5) * EBC_VN_SEGS + sg) * O + unit] = c;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -436,6 +489,59 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
 // ---- the per-pair glue of the value network (rl/policy/sarl.py:52-78), HBM-bound ------------------
 // A "pair" = one (env, action) joint state = R consecutive rows, of which the first n_valid[b] exist
 // (NULL: all R).  One wave per pair; lanes walk the feature dimension in 16-byte vectors, rows serially.
+
+// w[b][r] = exp(s) (s != 0) (r < n_valid) / sum over the pair (sarl.py:69-71): the row weights the feature block folds
+// into its epilogue (MlpExtra.row_weight).  One thread per pair.
+__global__ __launch_bounds__(256) void pair_weights_kernel(const float *scores, const long long *n_valid, int B, int R, float *w) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int nv = n_valid ? (int)n_valid[b] : R;
+  const float *s = scores + (size_t)b * R;
+  float sum = 0.0f;
+  for (int r = 0; r < R; ++r) {
+    const float v = s[r];
+    sum += (r < nv && v != 0.0f) ? expf(v) : 0.0f;
+  }
+  for (int r = 0; r < R; ++r) {
+    const float v = s[r];
+    w[(size_t)b * R + r] = r < nv ? (v != 0.0f ? expf(v) : 0.0f) / sum : 0.0f;  // padding rows: exactly 0, whatever the sum
+  }
+}
+
+// 1 for the rows of a pair that exist, 0 for its padding (the weights of a masked mean).
+__global__ __launch_bounds__(256) void pair_mask_kernel(const long long *n_valid, int B, int R, float *w) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (size_t)B * R) return;
+  const int b = (int)(q / R), r = (int)(q - (size_t)b * R);
+  w[q] = r < (int)n_valid[b] ? 1.0f : 0.0f;
+}
+
+// out[b][:] = the sum of the tile partials of pair b's rows (MlpExtra.partial), divided by the pair's row count when
+// `mean`.  One wave per pair; a pair of R <= 32 rows lies in at most two tiles.
+__global__ __launch_bounds__(256) void pair_combine_kernel(const double *partial, const long long *n_valid, int B, int R, int O, int mean,
+                                                           float *out) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const int t0 = (int)(((long long)b * R) >> 5), t1 = (int)(((long long)b * R + R - 1) >> 5);
+  double denom = 1.0;
+  if (mean) {
+    const int nv = n_valid ? (int)n_valid[b] : R;
+    denom = (double)(nv < 1 ? 1 : nv);
+  }
+  for (int c = lane * 4; c + 3 < O; c += 256) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int t = t0; t <= t1; ++t) {
+      const int sg = b - (t * 32) / R;
+      const double *src = partial + ((size_t)t * EBC_VN_SEGS + sg) * O + c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += src[k];
+    }
+    vn_f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = (float)(mean ? acc[k] / denom : acc[k]);
+    *reinterpret_cast<vn_f32x4 *>(out + (size_t)b * O + c) = v;
+  }
+}
 
 // g[b] = mean over the pair's rows of h[b][r][:]  (sarl.py:56-58: the global state), one pass over h.
 __global__ __launch_bounds__(256) void pair_mean_kernel(const float *h, const long long *n_valid, int B, int R, int H,

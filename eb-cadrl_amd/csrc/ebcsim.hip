@@ -1222,6 +1222,12 @@ int launch_mlp2_shape(const Mlp2 *m, hipStream_t st, const float *x, int M, int 
     raised = lds;
   }
   constexpr int rows = 32 * NW;
+  {  // the row-group sums live in the coalesced-output epilogue (ebc_value_net.h): the block must be one that takes it
+    constexpr size_t a_size = (size_t)TI * 256, b_size = (size_t)TO * 256;
+    constexpr size_t per_u = LEAN == 2 ? (a_size + b_size + 1) / 2 : LEAN ? (2 * a_size + b_size + 1) / 2 : a_size + b_size;
+    if (ex.partial && !((m->O & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= per_u * 2 * 16))
+      return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_reduce: this block shape has no tile epilogue");
+  }
   const dim3 grid((unsigned)((M + rows - 1) / rows)), block(64 * NW);
   if (ex.row_bias)
     hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
@@ -1263,6 +1269,18 @@ int launch_mlp2(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_o
     case 6: return launch_mlp2_to<TI, 6>(m, st, x, M, relu_out, y, ex);
     case 7: return launch_mlp2_to<TI, 7>(m, st, x, M, relu_out, y, ex);
     default: return fail(EBC_ERR_UNSUPPORTED, "mlp2: more than 224 outputs");
+  }
+}
+
+int mlp2_dispatch(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
+  switch (m->L1.in_tiles) {
+    case 1: return launch_mlp2<1>(m, st, x, M, relu_out, y, ex);
+    case 2: return launch_mlp2<2>(m, st, x, M, relu_out, y, ex);
+    case 3: return launch_mlp2<3>(m, st, x, M, relu_out, y, ex);
+    case 4: return launch_mlp2<4>(m, st, x, M, relu_out, y, ex);
+    case 5: return launch_mlp2<5>(m, st, x, M, relu_out, y, ex);
+    case 6: return launch_mlp2<6>(m, st, x, M, relu_out, y, ex);
+    default: return launch_mlp2<7>(m, st, x, M, relu_out, y, ex);
   }
 }
 
@@ -1308,16 +1326,49 @@ int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_ou
   if (M == 0) return EBC_OK;
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = (hipStream_t)stream;
-  const ebc::MlpExtra ex = {row_bias, group_rows, m->H, m->final_w, m->final_b};
-  switch (m->L1.in_tiles) {
-    case 1: return launch_mlp2<1>(m, st, x, M, relu_out, y, ex);
-    case 2: return launch_mlp2<2>(m, st, x, M, relu_out, y, ex);
-    case 3: return launch_mlp2<3>(m, st, x, M, relu_out, y, ex);
-    case 4: return launch_mlp2<4>(m, st, x, M, relu_out, y, ex);
-    case 5: return launch_mlp2<5>(m, st, x, M, relu_out, y, ex);
-    case 6: return launch_mlp2<6>(m, st, x, M, relu_out, y, ex);
-    default: return launch_mlp2<7>(m, st, x, M, relu_out, y, ex);
-  }
+  const ebc::MlpExtra ex = {row_bias, group_rows, m->H, m->final_w, m->final_b, nullptr, nullptr, 0, 1};
+  return mlp2_dispatch(m, st, x, M, relu_out, y, ex);
+}
+
+int ebc_mlp2_forward_reduce(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
+                            int group_rows, float *y, int seg_rows, const float *row_weight, double *partial) {
+  Mlp2 *m = (Mlp2 *)mlp;
+  if (!m || !x || !partial || M < 0) return fail(EBC_ERR_INVALID, "mlp2 forward_reduce arguments");
+  if (row_bias && group_rows <= 0) return fail(EBC_ERR_INVALID, "mlp2: group_rows");
+  if (m->final_w) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_reduce: a block with a one-output third layer has no [M][O] rows");
+  if (seg_rows < 16) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_reduce: groups of fewer than 16 rows (a tile would touch more than three)");
+  if (m->O & 3) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_reduce: O must be a multiple of 4");
+  if (M == 0) return EBC_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  const ebc::MlpExtra ex = {row_bias, group_rows, m->H, nullptr, 0.0f, row_weight, partial, seg_rows, y ? 1 : 0};
+  return mlp2_dispatch(m, (hipStream_t)stream, x, M, relu_out, y, ex);
+}
+
+int ebc_pair_weights(void *stream, const float *scores, const long long *n_valid, int B, int R, float *w) {
+  if (!scores || !w || B < 0 || R <= 0) return fail(EBC_ERR_INVALID, "pair_weights arguments");
+  if (B == 0) return EBC_OK;
+  hipLaunchKernelGGL(ebc::pair_weights_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, n_valid, B, R, w);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+int ebc_pair_mask(void *stream, const long long *n_valid, int B, int R, float *w) {
+  if (!n_valid || !w || B < 0 || R <= 0) return fail(EBC_ERR_INVALID, "pair_mask arguments");
+  if (B == 0) return EBC_OK;
+  const size_t n = (size_t)B * R;
+  hipLaunchKernelGGL(ebc::pair_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_valid, B, R, w);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+int ebc_pair_combine(void *stream, const double *partial, const long long *n_valid, int B, int R, int O, int mean, float *out) {
+  if (!partial || !out || B < 0 || R < 16 || R > 32 || O <= 0) return fail(EBC_ERR_INVALID, "pair_combine arguments (16 <= R <= 32)");
+  if ((O & 3) || (((size_t)partial | (size_t)out) & 15)) return fail(EBC_ERR_INVALID, "pair_combine: O a multiple of 4, 16-byte aligned buffers");
+  if (B == 0) return EBC_OK;
+  hipLaunchKernelGGL(ebc::pair_combine_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, partial, n_valid, B, R, O,
+                     mean, out);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
 }
 
 int ebc_pair_mean(void *stream, const float *h, const long long *n_valid, int B, int R, int H, float *g) {

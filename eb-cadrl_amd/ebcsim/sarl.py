@@ -63,6 +63,23 @@ class _NativeMlp2(object):
                                              y.data_ptr()))
         return y
 
+    def reduce(self, x, relu_out, seg_rows, row_weight=None, store=True):
+        """The block with the row-group sums folded into its epilogue (ebc_mlp2_forward_reduce): -> (y or None,
+        partial [ceil(M / 32)][3][O]) — ebc_pair_combine turns the partials into per-pair means / weighted sums."""
+        from . import _capi
+        x = x.contiguous()
+        M = int(x.shape[0])
+        y = torch.empty((M, self.O), dtype=torch.float32, device=x.device) if store else None
+        partial = torch.empty(((M + 31) // 32, 3, self.O), dtype=torch.float64, device=x.device)
+        if row_weight is not None:
+            row_weight = row_weight.contiguous()
+        _capi.check(self._L.ebc_mlp2_forward_reduce(self._h, torch.cuda.current_stream(x.device).cuda_stream,
+                                                    x.data_ptr(), M, int(bool(relu_out)), None, 0,
+                                                    None if y is None else y.data_ptr(), int(seg_rows),
+                                                    None if row_weight is None else row_weight.data_ptr(),
+                                                    partial.data_ptr()))
+        return y, partial
+
     def __del__(self):
         try:
             self._L.ebc_mlp2_destroy(self._h)
@@ -119,6 +136,13 @@ class SarlValueNet(object):
                     # ... and its last two layers (the reference's 200 -> 200 -> 1) as a block with one output
                     if len(self.mlp3) == 4 and self.mlp3[2][0].shape[1] <= 224 and self.mlp3[3][0].shape[0] <= 224:
                         blocks.append(_NativeMlp2(self.mlp3[2:4], idx))
+                # the mean state's half of attention layer 0 (one 200 x 200 layer per PAIR) as a block too: the mean of
+                # ReLU outputs is >= 0, so relu(I g) = g and [I | w0[:, H:]] is that layer in the two-layer form
+                eye = torch.eye(H, dtype=torch.float32, device=self.device)
+                self._gterm_block = None
+                if self.attention[0][0].shape[0] <= 224:
+                    self._gterm_block = _NativeMlp2([(eye, torch.zeros(H, dtype=torch.float32, device=self.device)),
+                                                     (self.attention[0][0][:, H:], self.attention[0][1])], idx)
                 self._native = tuple(blocks)
             else:
                 self._native = ()
@@ -145,6 +169,36 @@ class SarlValueNet(object):
                                                 feat.data_ptr(), None if nv64 is None else nv64.data_ptr(), B, R,
                                                 int(feat.shape[2]), out.data_ptr()))
         return out
+
+    @staticmethod
+    def _pair_combine(partial, nv64, B, R, mean):
+        """Per-pair sums of a block's tile partials (libebcsim ebc_pair_combine): the pair mean (sarl.py:56-58) or,
+        with the attention weights as row weights, the weighted feature sum (sarl.py:73-76)."""
+        from . import _capi
+        O = int(partial.shape[2])
+        out = torch.empty((B, O), dtype=torch.float32, device=partial.device)
+        _capi.check(_capi.lib().ebc_pair_combine(torch.cuda.current_stream(partial.device).cuda_stream, partial.data_ptr(),
+                                                 None if nv64 is None else nv64.data_ptr(), B, R, O, int(bool(mean)),
+                                                 out.data_ptr()))
+        return out
+
+    @staticmethod
+    def _pair_weights(scores, nv64, B, R):
+        """softmax' of the pair's scores (sarl.py:69-71) as row weights [B * R] (libebcsim ebc_pair_weights)."""
+        from . import _capi
+        scores = scores.contiguous()
+        w = torch.empty((B * R,), dtype=torch.float32, device=scores.device)
+        _capi.check(_capi.lib().ebc_pair_weights(torch.cuda.current_stream(scores.device).cuda_stream, scores.data_ptr(),
+                                                 None if nv64 is None else nv64.data_ptr(), B, R, w.data_ptr()))
+        return w
+
+    @staticmethod
+    def _pair_mask(nv64, B, R):
+        from . import _capi
+        w = torch.empty((B * R,), dtype=torch.float32, device=nv64.device)
+        _capi.check(_capi.lib().ebc_pair_mask(torch.cuda.current_stream(nv64.device).cuda_stream, nv64.data_ptr(), B, R,
+                                              w.data_ptr()))
+        return w
 
     @classmethod
     def load(cls, path, device="cpu", **kw):
@@ -187,6 +241,34 @@ class SarlValueNet(object):
         rows = rows.to(getattr(self, "dtype", torch.float32))
         self_state = rows[:, 0, :self.self_state_dim]
         nat = None if torch.is_grad_enabled() or not rows.is_cuda or exact else self._native_blocks()
+        nv64 = None if n_valid is None else n_valid.to(torch.int64).contiguous()
+        # The pair reductions folded into the blocks that produce the rows (16 <= R <= 32: a 32-row tile touches at
+        # most three pairs): mlp1 leaves the pair sums of h1 beside h1, the attention stack runs BEFORE mlp2, and
+        # mlp2 multiplies its rows by the attention weights and leaves only their pair sums — the [B * R][F]
+        # features are never written, nothing reads h1 a second time for the mean.
+        folded = (nat is not None and self.with_global_state and 16 <= R <= 32 and not want_weights
+                  and getattr(self, "fold_pairs", True) and nat[0].O % 4 == 0 and nat[1].O % 4 == 0)
+        if folded:
+            self.native_forwards = getattr(self, "native_forwards", 0) + 1
+            self.folded_forwards = getattr(self, "folded_forwards", 0) + 1
+            mask = None if nv64 is None else self._pair_mask(nv64, B, R)
+            h1, part = nat[0].reduce(rows.reshape(B * R, T), True, R, mask)
+            g = self._pair_combine(part, nv64, B, R, True)
+            if self._gterm_block is not None:
+                gterm = self._gterm_block(g, False)
+            else:
+                w0, b0 = self.attention[0]
+                gterm = torch.nn.functional.linear(g, w0[:, h1.shape[1]:], b0)
+            scores = nat[2](h1, False, row_bias=gterm, group_rows=R)
+            w = self._pair_weights(scores, nv64, B, R)
+            _, part = nat[1].reduce(h1, False, R, w, store=False)
+            attended = self._pair_combine(part, None, B, R, False)
+            joint = torch.cat([self_state, attended], dim=1)
+            if len(nat) > 4:
+                return nat[4](nat[3](joint, True), False).squeeze(1)
+            if len(nat) > 3:
+                return _mlp(nat[3](joint, True), self.mlp3[2:], False).squeeze(1).to(torch.float32)
+            return _mlp(joint, self.mlp3, False).squeeze(1).to(torch.float32)
         if nat is not None:
             self.native_forwards = getattr(self, "native_forwards", 0) + 1  # tests assert the HIP path ran
             h1 = nat[0](rows.reshape(B * R, T), True)
@@ -198,7 +280,6 @@ class SarlValueNet(object):
         # where they replace a dozen element-wise launches)
         fused = ((nat is not None or (exact and rows.is_cuda and not torch.is_grad_enabled()))
                  and h1.shape[1] % 4 == 0 and feat.shape[2] % 4 == 0 and feat.shape[2] <= 256)
-        nv64 = None if n_valid is None else n_valid.to(torch.int64).contiguous()
         if fused or n_valid is None:
             valid = None
             denom = float(R)

@@ -391,6 +391,25 @@ int ebc_pair_mean(void *stream, const float *h, const long long *n_valid, int B,
 int ebc_pair_attend(void *stream, const float *scores, const float *feat, const long long *n_valid, int B, int R,
                     int F, float *out);
 
+/* The same two reductions folded into the block that PRODUCES the activations, so that no second pass reads them
+ * (and the features the attention weights multiply are never written at all):
+ *   ebc_mlp2_forward_reduce: ebc_mlp2_forward, and per 32-row tile the row-weighted sums of y over each group of
+ *     seg_rows (16 <= seg_rows, = R) consecutive rows the tile touches: partial [ceil(M / 32)][3][O] (device, float64).
+ *     row_weight [M] (device; NULL = 1).  y NULL: the activations are not stored.  O a multiple of 4.
+ *   ebc_pair_weights: w [B][R] = softmax'(scores) of ebc_pair_attend — the row weights of the feature block.
+ *   ebc_pair_mask:    w [B][R] = 1 for rows < n_valid[b], else 0 — the row weights of a masked mean.
+ *   ebc_pair_combine: out [B][O] = the sum of pair b's partials (two or three tiles), / n_valid[b] when mean != 0:
+ *     with row weights 1 (or the mask) the pair mean of sarl.py:56-58, with ebc_pair_weights the weighted feature
+ *     sum of sarl.py:73-76.  The sums are carried in float64 (float32 x float32 products are exact there) and rounded
+ *     to float32 once: the result does not depend on where in the batch a pair's rows lie, and equals the one-pass
+ *     kernels' to float32 rounding. */
+int ebc_mlp2_forward_reduce(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
+                            int group_rows, float *y, int seg_rows, const float *row_weight, double *partial);
+int ebc_pair_weights(void *stream, const float *scores, const long long *n_valid, int B, int R, float *w);
+int ebc_pair_mask(void *stream, const long long *n_valid, int B, int R, float *w);
+int ebc_pair_combine(void *stream, const double *partial, const long long *n_valid, int B, int R, int O, int mean,
+                     float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,3 +107,89 @@ def test_pair_glue_matches_torch(B, R, H, F, ragged):
     torch.cuda.synchronize()
     torch.testing.assert_close(got_g, ref_g, atol=2e-6, rtol=1e-5)
     torch.testing.assert_close(got_o, ref_o, atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K0,H,O,R,B,ragged,store", [(17, 300, 200, 18, 777, False, True), (200, 200, 100, 18, 1031, True, False),
+                                                     (13, 150, 100, 16, 65, True, True), (40, 64, 52, 32, 33, False, False),
+                                                     (17, 300, 200, 23, 101, True, True)])
+def test_mlp2_reduce_epilogue_gives_pair_sums(K0, H, O, R, B, ragged, store):
+    """ebc_mlp2_forward_reduce + ebc_pair_combine: the rows of the block equal ebc_mlp2_forward's bit for bit, and the
+    per-pair (weighted, masked) sums equal the sums of those rows in float64 to float32 rounding — the mean of
+    sarl.py:56-58 with the mask as weights, the attention-weighted feature sum of sarl.py:73-76 with
+    ebc_pair_weights; with store = 0 the rows are not written at all."""
+    import torch
+    from ebcsim import _capi
+    L = _lib()
+    rs = np.random.RandomState(K0 + 7 * R + B)
+    M = B * R
+    w1 = (rs.randn(H, K0) / np.sqrt(K0)).astype(np.float32)
+    b1 = (rs.randn(H) * 0.1).astype(np.float32)
+    w2 = (rs.randn(O, H) / np.sqrt(H)).astype(np.float32)
+    b2 = (rs.randn(O) * 0.1).astype(np.float32)
+    x = (rs.randn(M, K0) * 2).astype(np.float32)
+    nv = rs.randint(1, R + 1, size=B).astype(np.int64) if ragged else None
+    h = C.c_void_p()
+    _capi.check(L.ebc_mlp2_create(0, K0, H, O, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data, None, None, C.byref(h)))
+    xd = torch.from_numpy(x).cuda()
+    plain = torch.zeros((M, O), dtype=torch.float32, device="cuda")
+    _capi.check(L.ebc_mlp2_forward(h, None, xd.data_ptr(), M, 1, None, 0, plain.data_ptr()))
+    nvd = None if nv is None else torch.from_numpy(nv).cuda()
+    nvp = None if nvd is None else nvd.data_ptr()
+    # (a) mean: weights = the mask (or none)
+    wd = None
+    if nvd is not None:
+        wd = torch.zeros(M, dtype=torch.float32, device="cuda")
+        _capi.check(L.ebc_pair_mask(None, nvp, B, R, wd.data_ptr()))
+    yd = torch.full((M, O), -7.0, dtype=torch.float32, device="cuda")
+    part = torch.full(((M + 31) // 32, 3, O), float("nan"), dtype=torch.float64, device="cuda")
+    _capi.check(L.ebc_mlp2_forward_reduce(h, None, xd.data_ptr(), M, 1, None, 0, yd.data_ptr() if store else None, R,
+                                          None if wd is None else wd.data_ptr(), part.data_ptr()))
+    mean = torch.zeros((B, O), dtype=torch.float32, device="cuda")
+    _capi.check(L.ebc_pair_combine(None, part.data_ptr(), nvp, B, R, O, 1, mean.data_ptr()))
+    torch.cuda.synchronize()
+    rows = plain.cpu().numpy().astype(np.float64).reshape(B, R, O)
+    if store:
+        np.testing.assert_array_equal(yd.cpu().numpy(), plain.cpu().numpy())
+    else:
+        assert (yd.cpu().numpy() == -7.0).all()
+    valid = np.ones((B, R)) if nv is None else (np.arange(R)[None, :] < nv[:, None]).astype(np.float64)
+    want = (rows * valid[:, :, None]).sum(1) / valid.sum(1)[:, None]
+    np.testing.assert_allclose(mean.cpu().numpy(), want, rtol=2e-6, atol=2e-6 * np.abs(rows).max())
+    # (b) attention-weighted sum: weights = softmax' of random scores (some exactly 0: masked by the reference's rule)
+    sc = rs.randn(B, R).astype(np.float32)
+    sc[rs.rand(B, R) < 0.1] = 0.0
+    sc[:, 0] = np.where(sc[:, 0] == 0, 0.5, sc[:, 0])  # at least one live row per pair
+    scd = torch.from_numpy(sc).cuda()
+    w = torch.zeros(M, dtype=torch.float32, device="cuda")
+    _capi.check(L.ebc_pair_weights(None, scd.data_ptr(), nvp, B, R, w.data_ptr()))
+    _capi.check(L.ebc_mlp2_forward_reduce(h, None, xd.data_ptr(), M, 1, None, 0, None, R, w.data_ptr(), part.data_ptr()))
+    att = torch.zeros((B, O), dtype=torch.float32, device="cuda")
+    _capi.check(L.ebc_pair_combine(None, part.data_ptr(), None, B, R, O, 0, att.data_ptr()))
+    old = torch.zeros((B, O), dtype=torch.float32, device="cuda")
+    _capi.check(L.ebc_pair_attend(None, scd.data_ptr(), plain.data_ptr(), nvp, B, R, O, old.data_ptr()))
+    torch.cuda.synchronize()
+    e = np.exp(sc.astype(np.float64)) * (sc != 0) * valid
+    wt = e / e.sum(1, keepdims=True)
+    np.testing.assert_allclose(w.cpu().numpy().reshape(B, R), wt, rtol=3e-6, atol=1e-7)
+    want = (rows * wt[:, :, None]).sum(1)
+    np.testing.assert_allclose(att.cpu().numpy(), want, rtol=3e-6, atol=3e-6 * np.abs(rows).max())
+    np.testing.assert_allclose(att.cpu().numpy(), old.cpu().numpy(), rtol=3e-6, atol=3e-6 * np.abs(rows).max())
+    _capi.check(L.ebc_mlp2_destroy(h))
+
+
+@pytest.mark.gpu
+def test_mlp2_reduce_refuses_what_it_cannot_do():
+    import torch
+    from ebcsim import _capi
+    L = _lib()
+    rs = np.random.RandomState(1)
+    w1, b1 = rs.randn(8, 5).astype(np.float32), rs.randn(8).astype(np.float32)
+    w2, b2 = rs.randn(4, 8).astype(np.float32), rs.randn(4).astype(np.float32)
+    h = C.c_void_p()
+    _capi.check(L.ebc_mlp2_create(0, 5, 8, 4, w1.ctypes.data, b1.ctypes.data, w2.ctypes.data, b2.ctypes.data, None, None, C.byref(h)))
+    x = torch.zeros((64, 5), device="cuda")
+    part = torch.zeros((2, 3, 4), dtype=torch.float64, device="cuda")
+    assert L.ebc_mlp2_forward_reduce(h, None, x.data_ptr(), 64, 1, None, 0, None, 8, None, part.data_ptr()) == -2  # EBC_ERR_UNSUPPORTED: groups of 8 rows
+    assert L.ebc_mlp2_forward_reduce(h, None, x.data_ptr(), 64, 1, None, 0, None, 16, None, part.data_ptr()) == -2  # a block of 1 + 1 tiles has no tile epilogue
+    _capi.check(L.ebc_mlp2_destroy(h))
