@@ -289,6 +289,16 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
   // (7 + 7 tiles: 224): one hidden accumulator instead of two, output tiles two at a time, the group term
   // read after the hidden MFMAs instead of held across them — the partner wave covers the dependent issue.
   constexpr bool TIGHT = (TI + TO) * 16 >= 224;
+  // Dimensions are padded to tiles of 32, the MFMA's k-step is 16: when the real input (hidden) width ends in the
+  // first half of its last tile, that tile's second k-step multiplies zeros — skipped (200 = 6 tiles + 8: one
+  // k-step in 14 of either layer; wave-uniform conditions).
+#ifdef EBC_VN_KSKIP
+  const bool skip_in = K0 <= 32 * TI - 16;
+  const int last_full = (ex.H <= 32 * hidden_tiles - 16) ? hidden_tiles - 1 : hidden_tiles;  // tiles before it use both k-steps
+#else  // measured: no gain (the conditions cost the attention shape 16 more spilled registers)
+  constexpr bool skip_in = false;
+  const int last_full = hidden_tiles;
+#endif
   for (int u = 0; u < hidden_tiles; ++u) {
     const int buf = u & 1;
     // this tile's group term first (its wait, after the first batch of MFMAs below, then also waits for
@@ -326,6 +336,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
     for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (i == TI - 1 && s == 1 && skip_in) continue;
         const Frag2 wf = frag(i, s);
         constexpr int first = 1;  // three MFMAs per step: 1 0 1 | 0 1 0 | ... never the same accumulator twice in a row
         const int p = TIGHT ? 0 : (((i * 2 + s) & 1) ? 1 - first : first);
@@ -355,6 +366,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
     if (!TIGHT) tile_frags(hid, true, hf);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
+      if (s == 1 && u >= last_full) continue;
       if (TIGHT) {  // one k-step's fragment at a time: eight registers fewer live across the output MFMAs
         float v[8];
 #pragma unroll
