@@ -348,7 +348,7 @@ def also_kernels(env, batch, dev, cfg_s=None):
         macs = float(Ed) * A * (R * row_macs + pair_macs)
         tf = 3.0 * 2.0 * macs / (ms * 1e-3) / 1e12  # three bf16 MFMA products per float32 product
         out.append({"kernel": "decision: %d envs x %d actions x %d rows, look-ahead sweep + SARL x2 network (split-bf16 MFMA "
-                              "blocks, pair kernels, float32 tail) + top-2 float32 refinement + argmax" % (Ed, A, R),
+                              "blocks with the pair mean / attention sum in their epilogues) + top-2 float32 refinement + argmax" % (Ed, A, R),
                     "ms_per_decision_batch": ms, "decisions_per_s": Ed / (ms * 1e-3),
                     "native_blocks": bool(net._native_blocks()),
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
