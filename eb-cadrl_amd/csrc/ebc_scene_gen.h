@@ -127,13 +127,11 @@ EBC_HD void sincos_dd(double angle, double &c_out, double &s_out) {
   // pi/2 to 107 bits
   const double P_HI = 1.5707963267948966, P_LO = 6.123233995736766e-17;
   const int k = (int)nearbyint(angle / P_HI);  // 0..4
-  DD r = dd_two_sum(angle, -(double)k * P_HI);
-  {  // k * P_HI is not exact for k = 3: subtract its rounding error too, then k * P_LO
-    const double p = (double)k * P_HI, pe = fma((double)k, P_HI, -p);
-    r = dd_two_sum(angle, -p);
-    r = dd_add(r, DD{-pe, 0.0});
-    r = dd_add(r, dd_mul_d(DD{P_LO, 0.0}, -(double)k));
-  }
+  // r = angle - k pi/2: k * P_HI is not exact for k = 3, so its rounding error is subtracted too, then k * P_LO
+  const double p = (double)k * P_HI, pe = fma((double)k, P_HI, -p);
+  DD r = dd_two_sum(angle, -p);
+  r = dd_add(r, DD{-pe, 0.0});
+  r = dd_add(r, dd_mul_d(DD{P_LO, 0.0}, -(double)k));
   const DD r2 = dd_mul(r, r);
   // sin r = r - r^3/3! + ..., cos r = 1 - r^2/2! + ...; |r| <= pi/4 + eps: 14 terms reach 2^-100
   DD ts = r, tc = DD{1.0, 0.0}, ss = r, cs = DD{1.0, 0.0};

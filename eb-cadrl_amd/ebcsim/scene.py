@@ -103,9 +103,18 @@ class SceneConfig:
 
 
 def max_static_rows(cfg: "SceneConfig") -> int:
-    """Upper bound on the observation rows of a generated map (static_rows): one per circle, and a wall of length
-    L (width 1) yields circles of radius sqrt(2)/2 every sqrt(2) along it: fewer than L of them."""
-    return (cfg.num_circles or 0) + (cfg.num_walls or 0) * max(int(cfg.max_wall_length), 1)
+    """Upper bound on the observation rows of a generated map (static_rows): one per circle; a wall of length L
+    (width 1) is covered by circles of radius sqrt(2)/2 every sqrt(2) along it, as many as `static_rows` steps
+    over its length (2 for L = 3)."""
+    def wall_rows(length):
+        rad = (0.5 - 0.0) * np.sqrt(2)
+        x, n = -length / 2.0 + rad, 0
+        while x < length / 2.0:
+            n += 1
+            x = x + 2 * rad
+        return max(n, 1)
+    longest = max((wall_rows(float(L)) for L in range(int(cfg.min_wall_length), int(cfg.max_wall_length) + 1)), default=1)
+    return (cfg.num_circles or 0) + (cfg.num_walls or 0) * longest
 
 
 _RULES = {"circle_crossing": _abi.RULE_CIRCLE_CROSSING, "square_crossing": _abi.RULE_SQUARE_CROSSING,

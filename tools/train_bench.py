@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--steps-per-iteration", type=int, default=4)
     ap.add_argument("--train-batches", type=int, default=20)
     ap.add_argument("--batch-size", type=int, default=100)
+    ap.add_argument("--device-scenes", action="store_true",
+                    help="every episode on a scene generated on the device from the train seeds (run_training scene_gen)")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -68,7 +70,14 @@ def main():
     env.reset(batch)
     t0 = sync()
     marks = []
-    hist = run_training(env, model, space, 0.9, il_steps=args.il_steps, il_epochs=args.il_epochs, train_iterations=args.iterations,
+    scene_kw = {}
+    if args.device_scenes:
+        from ebcsim import scene as ebc_scene
+        cfg_s = bench.scene_config("metric")
+        if ebc_scene.max_static_rows(cfg_s) > batch.S:
+            raise SystemExit("--device-scenes: the bench batch has fewer static rows than a generated map can need")
+        scene_kw = dict(scene_gen=ebc_scene.gen_struct(cfg_s, "train"), scene_seed0=2000 + rank * (1 << 24))
+    hist = run_training(env, model, space, 0.9, il_steps=args.il_steps, il_epochs=args.il_epochs, train_iterations=args.iterations, **scene_kw,
                         steps_per_iteration=args.steps_per_iteration, train_batches=args.train_batches,
                         batch_size=args.batch_size, capacity=max(100000, args.il_steps * args.envs), generator=g,
                         log=lambda line: marks.append((line.split(":")[0], sync())))
@@ -85,7 +94,8 @@ def main():
     if rank == 0:
         print(json.dumps({"world": world, "envs_per_gpu": args.envs, "humans": int(batch.N), "il_states_stored": stored,
                           "il_episodes": episodes, "il_loss": hist["il_loss"], "rl_loss": hist["rl_loss"],
-                          "rl_decisions": decisions, **times}))
+                          "rl_decisions": decisions, "scenes": "device" if args.device_scenes else "host batch",
+                          "scene_pools": hist.get("scene_pools", 0), **times}))
     if world > 1:
         dist.destroy_process_group()
 
