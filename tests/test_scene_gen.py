@@ -174,6 +174,14 @@ def test_sincos_is_within_one_ulp_of_numpy(host_gen):
         assert (got != want).mean() < 0.01
 
 
+def test_max_static_rows_bounds_generated_maps():
+    """scene.max_static_rows: what a handle needs as max_static to take any map of a config (walls of every length)."""
+    for c in list(_variants())[:2] + [sc for _, _, _, sc in _golden_cases() if sc.num_walls][::5]:
+        bound = ebc_scene.max_static_rows(c)
+        most = max(len(ebc_scene.generate_scene(c, s, "test").static_rows) for s in range(7000, 7060))
+        assert most <= bound <= most + (c.num_walls or 0), (bound, most)
+
+
 def test_static_row_overflow_is_reported(host_gen):
     c = next(_variants())
     gen = ebc_scene.gen_struct(c, "test")
