@@ -113,7 +113,9 @@ __device__ __forceinline__ void tile_frags(const f32x16 &acc, bool relu, Frag2 (
 // efficient of the three for that reason: its two workgroups drift apart and fill each other's waits).
 // LEAN 2: ONE slot for the L1 halves too (A | B): every half is staged one phase ahead into the slot the barrier just
 // passed has freed; for the shape whose lean layout is still too big to fit a CU twice (7 + 7 tiles).
-template <int TI, int TO, int NW, bool GROUP, int LEAN = 0>
+// KIN: the input is at most 32 TI - 16 wide, i.e. the second k-step of its last tile multiplies zeros: left out at
+// compile time (one layer-1 MFMA triple in 2 TI, and the eight registers of that fragment).
+template <int TI, int TO, int NW, bool GROUP, int LEAN = 0, int KIN = 0>
 __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 : 1)) void mlp2_split_wg_kernel(const float *X, int M, int K0, PackedLayer L1,
                                                            PackedLayer L2, int relu_out, float *Y, int O, MlpExtra ex) {
   extern __shared__ uint4 wbuf[];  // weights: A0 | B0 | A1 | B1 (LEAN: A0 | B | A1), then the hidden layer's biases
@@ -207,6 +209,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
+        if (KIN != 0 && i == TI - 1 && s2 == 1) continue;
         const vn_f32x4 a = xt[(col * EBC_VN_XROW + s2 * 64 + half * 32) / 16], b = xt[(col * EBC_VN_XROW + s2 * 64 + half * 32 + 16) / 16];
         const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
         x[i][s2][0] = split8(v);
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
     for (int u = 0; u < TI; ++u)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
+        if (KIN != 0 && u == TI - 1 && s == 1) continue;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -292,11 +296,10 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
   // Dimensions are padded to tiles of 32, the MFMA's k-step is 16: when the real input (hidden) width ends in the
   // first half of its last tile, that tile's second k-step multiplies zeros — skipped (200 = 6 tiles + 8: one
   // k-step in 14 of either layer; wave-uniform conditions).
-#ifdef EBC_VN_KSKIP
-  const bool skip_in = K0 <= 32 * TI - 16;
-  const int last_full = (ex.H <= 32 * hidden_tiles - 16) ? hidden_tiles - 1 : hidden_tiles;  // tiles before it use both k-steps
-#else  // measured: no gain (the conditions cost the attention shape 16 more spilled registers)
-  constexpr bool skip_in = false;
+  constexpr bool skip_in = KIN != 0;
+#ifdef EBC_VN_HSKIP  // experiment: the last hidden tile's empty second k-step skipped at run time
+  const int last_full = (ex.H <= 32 * hidden_tiles - 16) ? hidden_tiles - 1 : hidden_tiles;
+#else
   const int last_full = hidden_tiles;
 #endif
   for (int u = 0; u < hidden_tiles; ++u) {

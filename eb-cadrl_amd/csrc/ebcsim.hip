@@ -1207,8 +1207,8 @@ int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool ac
   return EBC_OK;
 }
 
-template <int TI, int TO, int NW, int LEAN>
-int launch_mlp2_shape(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
+template <int TI, int TO, int NW, int LEAN, int KIN>
+int launch_mlp2_kin(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
   const size_t weights = LEAN == 2 ? (size_t)(TI + TO) * 4096 : LEAN ? (size_t)(2 * TI + TO) * 4096 : 2 * (size_t)(TI + TO) * 4096;
   const size_t lds = (weights + 31) / 32 * 32 + (size_t)m->L1.out_tiles * 32 * 4 +
                      (ex.row_bias ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0);  // + the waves' parked group terms
@@ -1216,9 +1216,9 @@ int launch_mlp2_shape(const Mlp2 *m, hipStream_t st, const float *x, int M, int 
   size_t &raised = raised_dev[m->device & 63][ex.row_bias ? 1 : 0];
   if (lds > 65536 && lds > raised) {
     if (ex.row_bias)
-      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN, KIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     else
-      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, false, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, false, LEAN, KIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised = lds;
   }
   constexpr int rows = 32 * NW;
@@ -1230,11 +1230,20 @@ int launch_mlp2_shape(const Mlp2 *m, hipStream_t st, const float *x, int M, int 
   }
   const dim3 grid((unsigned)((M + rows - 1) / rows)), block(64 * NW);
   if (ex.row_bias)
-    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
+    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN, KIN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
   else
-    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, false, LEAN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
+    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, false, LEAN, KIN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
+}
+
+// 200-wide inputs (the h1 rows of mlp2 and of the attention stack) end in the first half of their seventh tile
+template <int TI, int TO, int NW, int LEAN>
+int launch_mlp2_shape(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
+  if constexpr (TI == 7) {
+    if (m->K0 <= 32 * TI - 16) return launch_mlp2_kin<TI, TO, NW, LEAN, 1>(m, st, x, M, relu_out, y, ex);
+  }
+  return launch_mlp2_kin<TI, TO, NW, LEAN, 0>(m, st, x, M, relu_out, y, ex);
 }
 
 template <int TI, int TO>
