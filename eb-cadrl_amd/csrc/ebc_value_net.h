@@ -5,7 +5,7 @@
 // instead into two bf16 numbers, x = hi + lo (hi = bf16(x), lo = bf16(x - hi)), and a product keeps
 // its three leading terms, hi*hi + hi*lo + lo*hi, accumulated in f32 by the MFMA: 16/3 the f32
 // matrix rate.  On the reference's decision runs the values move by at most 1.5e-5 (bar: 2e-4;
-// tools/split_bf16_accuracy.py); plain bf16 moves them by 7e-3 and changes half the decisions.
+// tests/split_bf16_accuracy.py); plain bf16 moves them by 7e-3 and changes half the decisions.
 //
 // Layout: layers are computed TRANSPOSED, H^T = W * X^T: the 32 samples of a tile sit on the lanes
 // (column = lane & 31), units on the rows of the 32x32 accumulator tile (row = (reg & 3) + 8 (reg >> 2)

@@ -1,5 +1,7 @@
+"""Checker script (uses the CPU oracle, so it lives under tests/): long full-size runs of the HIP step against the
+oracle, every env every step.  python tests/soak_parity.py (on the GPU box)."""
 import os, sys, json, time
-ROOT="/root/repo"
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT,"eb-cadrl_amd"), os.path.join(ROOT,"tests")): sys.path.insert(0,p)
 import numpy as np, torch, bench
 from ebcsim import _abi

@@ -3,7 +3,7 @@
 hi + lo and the cross terms are kept?  Emulated on the CPU (products of bf16 values are exact in
 f32, accumulation in f32 as the MFMA does) on the golden SARL decision runs.
 
-    python3 tools/split_bf16_accuracy.py
+    python3 tests/split_bf16_accuracy.py
 terms 1 = plain bf16, 3 = hi*hi + hi*lo + lo*hi, 4 = all four."""
 import json, os, sys
 import numpy as np, torch
