@@ -216,7 +216,13 @@ class EpisodeStore(object):
 
 
 def _multi_rank():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """A process group with more than one rank — or with one rank and EBCSIM_FORCE_COLLECTIVES=1: every collective of
+    the schedule then runs through the backend (RCCL on a one-GPU box: tests/test_train_gloo.py) instead of being
+    skipped as the identity it is."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    import os
+    return dist.get_world_size() > 1 or os.environ.get("EBCSIM_FORCE_COLLECTIVES") == "1"
 
 
 def all_ranks(flag, device=None):
@@ -247,7 +253,7 @@ def broadcast_parameters_(model, src=0):
 
 def allreduce_flat_(params):
     """Average the gradients of `params` over ranks with ONE all-reduce of a flat buffer."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _multi_rank():
         return
     grads = [p.grad for p in params if p.grad is not None]
     flat = torch.cat([g.reshape(-1) for g in grads])

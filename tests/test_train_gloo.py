@@ -265,6 +265,61 @@ def test_run_training_on_device_generated_scenes():
     assert len({float(st["gx"][e, 0]) for e in range(E)}) > E // 2  # and not all the same scene
 
 
+RCCL_DRIVER = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "eb-cadrl_amd")); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import torch, torch.distributed as dist
+from helpers import batch_from_init, load, params_of
+from ebcsim.batched import BatchedEnv
+from ebcsim.train import SarlModule, run_training
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+if os.environ.get("EBCSIM_FORCE_COLLECTIVES") == "1":
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+z = load("sarl_a5_baseline")
+E = 32
+b = batch_from_init(z, copies=E)
+env = BatchedEnv(params_of(z), E, b.N, b.S)
+env.reset(b)
+env.use_torch_stream()
+torch.manual_seed(3)
+model = SarlModule(input_dim=13, mlp1_dims=[150, 100], mlp2_dims=[100, 50], mlp3_dims=[150, 100, 100, 1], attention_dims=[100, 100, 1]).to(dev)
+g = torch.Generator(device=dev).manual_seed(5)
+hist = run_training(env, model, z["action_space"], 0.9, il_steps=80, il_epochs=1, train_iterations=2, steps_per_iteration=3,
+                    train_batches=3, capacity=20000, epsilon_decay=2, generator=g)
+digest = float(sum(p.detach().double().abs().sum() for p in model.parameters()))
+print(json.dumps({"il_loss": hist["il_loss"], "rl_loss": hist["rl_loss"], "digest": digest,
+                  "backend": dist.get_backend() if dist.is_initialized() else None}))
+if dist.is_initialized():
+    dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_schedule_through_rccl_on_one_rank(tmp_path):
+    """Every collective of the schedule (the flat gradient all-reduce, the MIN all-reduce of the 'has data' flag, the
+    broadcasts of the start) through RCCL itself: a one-rank nccl process group with EBCSIM_FORCE_COLLECTIVES=1 on
+    the GPU must train exactly what the run without a process group trains (a sum over one rank is the identity)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_driver.py"
+    script.write_text(RCCL_DRIVER)
+    outs = []
+    for force in ("0", "1"):
+        env = dict(os.environ, EBCSIM_FORCE_COLLECTIVES=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["backend"] is None and outs[1]["backend"] == "nccl"
+    # (approx: two GPU training runs are not bit-reproducible to begin with)
+    assert outs[1]["il_loss"] == pytest.approx(outs[0]["il_loss"], rel=1e-4)
+    assert outs[1]["rl_loss"] == pytest.approx(outs[0]["rl_loss"], rel=1e-3)
+    assert outs[1]["digest"] == pytest.approx(outs[0]["digest"], rel=1e-5)
+
+
 def test_episode_store_keeps_successes_and_collisions_only():
     """explorer.py:82-92: pairs reach the memory when their episode ends, and only for ReachGoal or a
     collision; a timeout's pairs are dropped; an unfinished episode keeps waiting."""
