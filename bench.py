@@ -416,11 +416,14 @@ def main():
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # EBCSIM_FORCE_COLLECTIVES=1: a one-rank job still forms its process group and runs the barriers and the
+    # reductions through the backend (the RCCL path on a one-GPU box: tests/test_bench_launcher.py)
+    collective = world > 1 or os.environ.get("EBCSIM_FORCE_COLLECTIVES") == "1"
+    if collective:
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ebcsim import _abi
     from ebcsim.batched import BatchedEnv
@@ -437,7 +440,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -479,7 +482,7 @@ def main():
         blocks = [block() for _ in range(n_blocks)]
     # max over ranks per block, then the median block
     bt = torch.tensor([b[0] for b in blocks], dtype=torch.float64, device=dev if backend == "nccl" else None)
-    if world > 1:
+    if collective:
         dist.all_reduce(bt, op=dist.ReduceOp.MAX)
     order = sorted(range(len(blocks)), key=lambda i: float(bt[i]))
     mid = order[len(order) // 2]
@@ -550,7 +553,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(params, batch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

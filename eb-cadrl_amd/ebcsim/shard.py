@@ -29,7 +29,9 @@ def job_rate(elapsed_local, units_local, device=None):
     torch.distributed is not initialised (single process)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    import os
+    forced = os.environ.get("EBCSIM_FORCE_COLLECTIVES") == "1"  # a one-rank group still goes through its backend
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not forced):
         return float(elapsed_local), float(units_local)
     t = torch.tensor([float(elapsed_local)], dtype=torch.float64, device=device)
     u = torch.tensor([float(units_local)], dtype=torch.float64, device=device)

@@ -50,3 +50,25 @@ def test_parent_does_not_touch_the_gpu_before_spawning():
     main = src[src.index("def main():"):]
     assert main.index("launch_ranks(") < main.index("import torch")
     assert "os.exec" not in src
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_rank_through_rccl_on_one_rank():
+    """The rank program itself with its process group on RCCL: one rank on the one GPU there is, the barriers, the
+    MAX all-reduce of the block times and job_rate's reductions forced through the backend
+    (EBCSIM_FORCE_COLLECTIVES=1) — the calls an N-GPU run makes, on device tensors."""
+    import subprocess
+    env = dict(os.environ, EBCSIM_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", RANK="0",
+               LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "5",
+                        "--no-also", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 50 and line["value"] > 1e8
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "50", "--warmup", "5", "--no-also",
+                            "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    ref = json.loads(plain.stdout.strip().splitlines()[-1])
+    assert abs(line["value"] / ref["value"] - 1) < 0.2  # the same job with and without the group
