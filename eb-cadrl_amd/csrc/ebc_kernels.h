@@ -17,6 +17,11 @@
 #pragma once
 
 #include "ebc_device.h"
+
+// s_sleep units (64 cycles each) between two polls of a mailbox: 2049 consumer waves poll while the ORCA waves work
+#ifndef EBC_POLL_SLEEP
+#define EBC_POLL_SLEEP 2
+#endif
 #include "ebc_orca_group.h"
 #include "ebc_scene_gen.h"
 
@@ -539,7 +544,7 @@ __device__ __forceinline__ u32x4 velocity_wait(const uint4 *box, bool need, unsi
       if (waiting) atomicOr(fault, 1u);
       break;
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(EBC_POLL_SLEEP);
   }
   return v;
 }
@@ -553,7 +558,7 @@ __device__ __forceinline__ void mailbox_wait_epoch(unsigned *box, bool need, uns
       if (waiting) atomicOr(fault, 1u);
       break;
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(EBC_POLL_SLEEP);
   }
 }
 template <typename W>
@@ -1201,7 +1206,7 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
         if (wv || wd || wr) atomicOr(s.fault, 1u);
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(EBC_POLL_SLEEP);
     }
   }
   EBC_MARK(1);
