@@ -47,6 +47,12 @@ def main():
             ref = net.action_values(rows, reward, 0.9, refine=2)
             torch.cuda.synchronize()
             gap = torch.topk(want, 2, dim=1).values
+            # where the coarse pass ranks the float32 network's best action (1 = first): the refinement looks at the top two
+            best = want.argmax(1)
+            rank = 1 + (raw > raw.gather(1, best[:, None])).sum(1)
+            err = (raw - want).abs()
+            print("   coarse rank of the float32-best action: max %d, envs with rank > 1: %d; |value - float32| median %.1e, 99.9th percentile %.1e" % (
+                int(rank.max()), int((rank > 1).sum()), float(err.median()), float(torch.quantile(err.flatten()[:1000000].float(), 0.999))), flush=True)
             print("%s, after %d steps: max |value - float32| %.2e; same action as float32: %d / %d without refinement, "
                   "%d / %d with the top-2 refinement; smallest top-2 gap %.1e" % (
                       name, 10 * step, float((raw - want).abs().max()), int((raw.argmax(1) == want.argmax(1)).sum()), E,
