@@ -1357,6 +1357,9 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
   }
   b -= env_blocks;
   if (b < orca_blocks) {
+    // ahead of the ROWS / STATE waves that poll on the same SIMD, behind the ENV chain (priority 3):
+    // -0.08 us per step (profiles/r02_early_rows_ab.txt)
+    __builtin_amdgcn_s_setprio(1);
     const OrcaHot hot{hot_E, hot_N, hot_magic, hot_shift, hot_tile, hot_n_humans};
     if (EBC_ROLE_MASK & 2) orca_role<GS>(p_in, s_in, hot, hot_vel, hot_epoch, lds, b, lane);
     return;
