@@ -19,6 +19,12 @@
 #include "ebc_device.h"
 
 // s_sleep units (64 cycles each) between two polls of a mailbox: 2049 consumer waves poll while the ORCA waves work
+#ifndef EBC_ENV_PRIO
+#define EBC_ENV_PRIO 3
+#endif
+#ifndef EBC_ORCA_PRIO
+#define EBC_ORCA_PRIO 1
+#endif
 #ifndef EBC_POLL_SLEEP
 #define EBC_POLL_SLEEP 2
 #endif
@@ -1344,14 +1350,14 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
   }
   b -= orca_blocks;
   if (b < env_blocks) {
-    __builtin_amdgcn_s_setprio(3);  // the long dependent chain of the launch
+    __builtin_amdgcn_s_setprio(EBC_ENV_PRIO);  // the long dependent chain of the launch
     if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, g.epoch, lane);
     return;
   }
   b -= env_blocks;
 #else
   if (b < env_blocks) {
-    __builtin_amdgcn_s_setprio(3);  // the long dependent chain of the launch
+    __builtin_amdgcn_s_setprio(EBC_ENV_PRIO);  // the long dependent chain of the launch
     if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, g.epoch, lane);
     return;
   }
@@ -1359,7 +1365,7 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
   if (b < orca_blocks) {
     // ahead of the ROWS / STATE waves that poll on the same SIMD, behind the ENV chain (priority 3):
     // -0.08 us per step (profiles/r02_early_rows_ab.txt)
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(EBC_ORCA_PRIO);
     const OrcaHot hot{hot_E, hot_N, hot_magic, hot_shift, hot_tile, hot_n_humans};
     if (EBC_ROLE_MASK & 2) orca_role<GS>(p_in, s_in, hot, hot_vel, hot_epoch, lds, b, lane);
     return;
