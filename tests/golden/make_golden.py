@@ -659,10 +659,20 @@ def gen_known_answers(ref):
 
 
 # ------------------------------------------------- (ix) SARL decisions (look-ahead + value net)
+A3B3 = "configs/test_configs/test_env_configs/env_adults_3_bikes_3.config"
+A3B3S10 = "configs/test_configs/test_env_configs/env_adults_3_bikes_3_static_10.config"
+BASELINE_PTH = "model_weights/sarl_model_baseline.pth"
+# (name, env config, overrides, policy config, weights, test case, scene JSON or None)
 SARL_RUNS = [
-    ("sarl_a5_baseline", A5, None, P1, "model_weights/sarl_model_baseline.pth", 2),
+    ("sarl_a5_baseline", A5, None, P1, BASELINE_PTH, 2, None),
     ("sarl_n10_ebcadrl", BIG, N10, "data/eb-cadrl/policy_x2_agent_type.config",
-     "data/eb-cadrl/rl_model_val.pth", 1),
+     "data/eb-cadrl/rl_model_val.pth", 1, None),
+    # the other known-answer runs of tests/run_tests.py:23-41 (test_basic_simulation.py:10-23 on two more
+    # configs, test_scene_simulation.py:9-23 on the frozen scene): pass = ReachGoal
+    ("sarl_a3b3s2_baseline", A3B3S2, None, P1, BASELINE_PTH, 2, None),
+    ("sarl_a3b3_baseline", A3B3, None, P1, BASELINE_PTH, 2, None),
+    ("sarl_scene_a3b3s10_baseline", A3B3S10, None, P1, BASELINE_PTH, None,
+     "tests/test_scenes/test_scene_adults_3_bikes_3_static_10.json"),
 ]
 
 
@@ -674,7 +684,7 @@ def gen_sarl(ref):
     from simulator.utils.test_utils import configure_env_policy_robot
     os.makedirs(os.path.join(HERE, "weights"), exist_ok=True)
     RVO2_MODE["substitute"] = True
-    for name, env_path, overrides, pol_path, weights, case in SARL_RUNS:
+    for name, env_path, overrides, pol_path, weights, case, scene_json in SARL_RUNS:
         text = cfg_text(os.path.join(ref, env_path), overrides)
         cfg = parsed(text)
         tmp = write_tmp(text)
@@ -683,9 +693,14 @@ def gen_sarl(ref):
                                                          os.path.join(ref, weights))
         finally:
             os.unlink(tmp)
-        wname = name + ".pth"
+        wname = ("sarl_a5_baseline" if weights == BASELINE_PTH else name) + ".pth"  # one copy of the shipped file
         shutil.copy(os.path.join(ref, weights), os.path.join(HERE, "weights", wname))  # data fixture
-        ob, _ = env.reset("test", test_case=case, compute_local_map=False)
+        if scene_json is not None:  # tests/test_scene_simulation.py:16
+            os.makedirs(os.path.join(HERE, "scenes"), exist_ok=True)
+            shutil.copy(os.path.join(ref, scene_json), os.path.join(HERE, "scenes", os.path.basename(scene_json)))  # data file
+            ob, _ = env.reset("test", load_scene_path=os.path.join(ref, scene_json), compute_local_map=False)
+        else:
+            ob, _ = env.reset("test", test_case=case, compute_local_map=False)
         init = scene_arrays(env)
         acts, vals, infos, rewards = [], [], [], []
         done = False
@@ -703,8 +718,8 @@ def gen_sarl(ref):
                    action_space=np.array([[a[0], a[1]] for a in pol.action_space]),
                    params=jdump(ebc_config.params_to_dict(params)),
                    meta=jdump({"config": env_path, "policy_config": pol_path, "weights": wname,
-                               "gamma": pol.gamma, "seed_case": case, "final_info": infos[-1],
-                               "with_global_state": True}))
+                               "gamma": pol.gamma, "seed_case": case, "scene_json": scene_json,
+                               "final_info": infos[-1], "with_global_state": True}))
         save(name, **out)
         print("  %s: %d decisions, final info code %d" % (name, len(acts), infos[-1]))
     RVO2_MODE["substitute"] = False
@@ -721,7 +736,7 @@ def gen_sarl_rl_memory(ref):
     from rl.utils.memory import ReplayMemory
     from simulator.utils.test_utils import configure_env_policy_robot
     RVO2_MODE["substitute"] = True
-    name, env_path, overrides, pol_path, weights, case = SARL_RUNS[0]
+    name, env_path, overrides, pol_path, weights, case, _ = SARL_RUNS[0]
     text = cfg_text(os.path.join(ref, env_path), overrides)
     tmp = write_tmp(text)
     try:
@@ -760,7 +775,7 @@ def gen_trainer_steps(ref):
     from rl.policy.policy_factory import policy_factory
     from rl.utils.memory import ReplayMemory
     from rl.utils.trainer import Trainer
-    name, env_path, overrides, pol_path, weights, case = SARL_RUNS[0]
+    name, env_path, overrides, pol_path, weights, case, _ = SARL_RUNS[0]
     g = np.load(os.path.join(HERE, "sarl_a5_rl_memory.npz"))
     pol = policy_factory["sarl"]()
     pol.configure(parsed(open(os.path.join(ref, pol_path)).read()))
@@ -783,7 +798,7 @@ def gen_sarl_configs(ref):
     """The env / policy configuration of each SARL run as text (data the reference ships), for the tests
     that drive the facade with a policy OBJECT (which configures itself from such files)."""
     table = {}
-    for name, env_path, overrides, pol_path, weights, case in SARL_RUNS:
+    for name, env_path, overrides, pol_path, weights, case, _ in SARL_RUNS:
         table[name] = {"config_text": cfg_text(os.path.join(ref, env_path), overrides),
                        "policy_config_text": cfg_text(os.path.join(ref, pol_path))}
     with open(os.path.join(HERE, "sarl_configs.json"), "w") as f:

@@ -211,7 +211,10 @@ def _native_sarl_episode(name, backend, device):
     robot.set_policy(policy)
     policy.set_phase("test")
     policy.set_device(device)
-    ob, local_map = env.reset("test", test_case=meta["seed_case"])
+    if meta.get("scene_json"):  # tests/test_scene_simulation.py:16
+        ob, local_map = env.reset("test", load_scene_path=os.path.join(GOLDEN, "scenes", os.path.basename(meta["scene_json"])))
+    else:
+        ob, local_map = env.reset("test", test_case=meta["seed_case"])
     done, t, worst, agree = False, 0, 0.0, 0
     while not done:
         action = robot.act(ob, local_map=local_map, env=env)
@@ -231,14 +234,17 @@ def _native_sarl_episode(name, backend, device):
     assert env.orca_evaluations == t and env.backend_calls == 2 * t  # one sweep + one step per decision
 
 
-@pytest.mark.parametrize("name", ["sarl_a5_baseline"])
+KNOWN_SARL = ["sarl_a3b3s2_baseline", "sarl_a3b3_baseline", "sarl_scene_a3b3s10_baseline"]  # tests/run_tests.py:23-41
+
+
+@pytest.mark.parametrize("name", ["sarl_a5_baseline"] + KNOWN_SARL)
 def test_native_sarl_policy_cpu_backend(name):
     from oracle import oracle
     _native_sarl_episode(name, lambda p, E, N, S: oracle.OracleEnv(p, E, N, S), "cpu")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["sarl_a5_baseline", "sarl_n10_ebcadrl"])
+@pytest.mark.parametrize("name", ["sarl_a5_baseline", "sarl_n10_ebcadrl"] + KNOWN_SARL)
 def test_native_sarl_policy_gpu(name):
     _native_sarl_episode(name, None, "cuda:0")
 
@@ -263,4 +269,13 @@ def test_reference_rl_policy_and_explorer_drive_this_env():
     same actions as with the reference's own simulator, values within float32 noise, and ORCA
     evaluated once per real step although the policy asks 81 times."""
     out = _driver("episode", "sarl_a5_baseline")
+    assert out["max_value_err"] <= 5e-5 and out["orca_evaluations"] == out["steps"]
+
+
+@needs_reference
+@pytest.mark.parametrize("name", KNOWN_SARL)
+def test_reference_known_answer_runs_on_this_env(name):
+    """tests/run_tests.py:23-41 of the reference: run_basic_simulation on its other two configs and
+    run_scene_simulation on the frozen scene, with the reference's own SARL policy object on this env."""
+    out = _driver("episode", name)
     assert out["max_value_err"] <= 5e-5 and out["orca_evaluations"] == out["steps"]
