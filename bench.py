@@ -140,14 +140,18 @@ def cpu_baseline(params, batch, seconds_target=7.0):
     return out
 
 
-def launch_ranks(n, argv, extra_env=None, timeout=None):
+def launch_ranks(n, argv, extra_env=None, timeout=1800.0):
     """Start `n` fresh rank processes (one per GPU) running `argv`, with the torch.distributed.run
     environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT); relay rank 0's stdout.
     The reference scales out the same way — a pool of worker processes (rl/train.py:19,
     rl/utils/parallel_explorer.py:275-276).  The parent never touches a GPU and never exec()s.
-    Returns (exit code: first non-zero of any rank, rank 0's stdout)."""
+    All ranks are polled together: the first rank that exits non-zero (a HIP error, a reported
+    mailbox fault, OOM) ends the job — the survivors, which would sit in a barrier or an all-reduce
+    waiting for it, are killed and that rank's code is returned.  `timeout` seconds for the whole
+    job (exit code 124).  Returns (exit code, rank 0's stdout)."""
     import socket
     import subprocess
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -157,19 +161,31 @@ def launch_ranks(n, argv, extra_env=None, timeout=None):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.update(extra_env or {})
         procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, rc = b"", 0
+    chunks = []
+    drain = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    drain.start()  # rank 0's pipe is emptied while every rank is watched: a full pipe cannot stall it
+    rc, deadline = 0, (time.monotonic() + timeout) if timeout else None
     try:
-        out = procs[0].communicate(timeout=timeout)[0]
-        for p in procs:
-            code = p.wait(timeout=timeout)
-            rc = rc or code
-    except subprocess.TimeoutExpired:
-        rc = 124
+        pending = list(procs)
+        while pending and rc == 0:
+            for p in list(pending):
+                code = p.poll()
+                if code is not None:
+                    pending.remove(p)
+                    rc = rc or code
+            if pending and rc == 0:
+                if deadline is not None and time.monotonic() > deadline:
+                    rc = 124
+                else:
+                    time.sleep(0.05)
     finally:
         for p in procs:  # exact PIDs we started, nothing by pattern
             if p.poll() is None:
                 p.kill()
-    return rc, out.decode()
+        for p in procs:
+            p.wait()
+        drain.join(timeout=10)
+    return rc, b"".join(chunks).decode()
 
 
 # the reference's Python env.step, measured in the survey container.  Carried as
@@ -393,6 +409,10 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the look-ahead / value-network side measurements")
     ap.add_argument("--human-policy", default="orca", choices=["orca", "linear"],
                     help="diagnostic only: the headline metric is ORCA")
+    ap.add_argument("--rehearsal-gpu-ranks", type=int, default=0,
+                    help="EBCSIM_BENCH_BACKEND=gloo only: rehearse an N-rank job on a box with fewer GPUs — ranks >= this "
+                         "number build their env slice on the host and take part in every collective but never open the "
+                         "GPU (a one-GPU box admits few processes on its card); the line then says timing: rehearsal")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -408,14 +428,21 @@ def main():
 
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a HIP device (no CPU fallback)")
     # one process per GPU; EBCSIM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer
     # GPUs than ranks (ranks then share devices; timing is meaningless, the code path is not)
     backend = os.environ.get("EBCSIM_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    rehearsal = backend != "nccl"
+    # a rehearsal rank past --rehearsal-gpu-ranks: its slice of the scenes on the host and every collective of
+    # the job, no GPU work and no HIP context (it contributes its units and a time of zero)
+    on_gpu = not (rehearsal and args.rehearsal_gpu_ranks > 0 and rank >= args.rehearsal_gpu_ranks)
+    if on_gpu and not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (no CPU fallback)")
+    dev = None
+    if on_gpu:
+        local_rank = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    gpu_sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     # EBCSIM_FORCE_COLLECTIVES=1: a one-rank job still forms its process group and runs the barriers and the
     # reductions through the backend (the RCCL path on a one-GPU box: tests/test_bench_launcher.py)
     collective = world > 1 or os.environ.get("EBCSIM_FORCE_COLLECTIVES") == "1"
@@ -430,31 +457,39 @@ def main():
 
     E = args.envs or WORKLOADS[args.workload][2]
     params, batch = build_batch(args.workload, E, rank)
-    env = BatchedEnv(params, E, batch.N, batch.S, device=local_rank)
-    env.reset(batch)
-    env.use_torch_stream()
-    outs = env.alloc_step_outputs(("reward", "done", "info", "obs_rotated"))
     flags = _abi.FLAG_AUTO_RESET
     hp = _abi.HUMAN_ORCA if args.human_policy == "orca" else _abi.HUMAN_LINEAR
     kw = dict(human_policy=hp, robot_policy=_abi.ROBOT_LINEAR, flags=flags)
+    if on_gpu:
+        env = BatchedEnv(params, E, batch.N, batch.S, device=local_rank)
+        env.reset(batch)
+        env.use_torch_stream()
+        outs = env.alloc_step_outputs(("reward", "done", "info", "obs_rotated"))
+        step = lambda: env.step_device(outs, **kw)  # noqa: E731
+    else:
+        env = None
+        step = lambda: None  # noqa: E731
 
     def barrier():
-        torch.cuda.synchronize()
+        gpu_sync()
         if collective:
             dist.barrier()
-        torch.cuda.synchronize()
+        gpu_sync()
 
     for _ in range(args.warmup):
-        env.step_device(outs, **kw)
+        step()
     barrier()
 
     def block():
         """EXACTLY K steps between barrier + synchronize brackets -> (this rank's seconds, stream ms)."""
+        if not on_gpu:
+            barrier()
+            return 0.0, 0.0
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
         for _ in range(args.steps):
-            env.step_device(outs, **kw)
+            step()
         ev1.record()
         torch.cuda.synchronize()             # this rank's K steps are done ...
         dt = time.perf_counter() - t0        # ... its time; the job's time is the MAX over ranks (below)
@@ -464,20 +499,20 @@ def main():
     first = block()
     blocks = [first]
     n_blocks = 1
-    if first[0] < args.min_block_seconds:
+    from ebcsim import shard as _sh
+    # every rank takes the same decision: the first block's time is max-reduced BEFORE it is compared
+    first_max, _ = _sh.job_rate(first[0], 0.0, device=dev if backend == "nccl" else None)
+    if first_max < args.min_block_seconds:
         # A K-step block shorter than ~50 ms is over before the chip has left its idle clock (round 1:
         # 20 steps = 0.43 ms read 17 % low).  Keep stepping untimed for >= 0.3 s, then repeat the same
         # bracketed K-step block an odd number of times and report the MEDIAN block: `steps` and
-        # `ms_per_step x steps` still describe one block.  Every rank takes the same decisions (the
-        # first block's time is max-reduced before it is compared).
-        from ebcsim import shard as _sh
-        first_max, _ = _sh.job_rate(first[0], 0.0, device=dev if backend == "nccl" else None)
+        # `ms_per_step x steps` still describe one block.
         n_blocks = int(min(101, max(5, 2 * int(0.5 * args.min_block_seconds / max(first_max, 1e-6)) + 1)))
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 0.3:
             for _ in range(50):
-                env.step_device(outs, **kw)
-            torch.cuda.synchronize()
+                step()
+            gpu_sync()
         barrier()
         blocks = [block() for _ in range(n_blocks)]
     # max over ranks per block, then the median block
@@ -490,11 +525,13 @@ def main():
     block_spread = (float(bt.min()), float(bt.max()))
 
     # per-launch kernel duration: HIP events around every launch, in a separate untimed pass
-    env.timing(True)
-    for _ in range(min(args.steps, 200)):
-        env.step_device(outs, **kw)
-    kernel_ms, n_timed = env.timing_read(reset=True)
-    env.timing(False)
+    kernel_ms = None
+    if on_gpu:
+        env.timing(True)
+        for _ in range(min(args.steps, 200)):
+            step()
+        kernel_ms, n_timed = env.timing_read(reset=True)
+        env.timing(False)
 
     also = None
     if rank == 0 and world == 1 and not args.no_also and args.human_policy == "orca":
@@ -504,7 +541,8 @@ def main():
     elapsed_max, total_humans = shard.job_rate(elapsed, float(batch.n_humans.sum()),
                                               device=dev if backend == "nccl" else None)
     try:
-        env.synchronize()  # also reports a mailbox fault of any step above (EBC_ERR_DEVICE)
+        if on_gpu:
+            env.synchronize()  # also reports a mailbox fault of any step above (EBC_ERR_DEVICE)
     except Exception as e:
         sys.exit("bench.py: the device reported a fault during the timed steps: %r" % (e,))
 
@@ -516,11 +554,18 @@ def main():
         # kernel_ms = events around every single launch in a separate pass (they add ~2 us each)
         launch_ms = stream_ms / args.steps
         achieved = bytes_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-        traffic = valu = None  # PMC-measured, from the committed profile of this workload (profiles/)
+        traffic = valu = traffic_note = None  # PMC-measured, from the committed profile of this workload (profiles/)
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tpath) and world == 1:
             tj = json.load(open(tpath))
-            if tj.get("envs_per_gpu") == E:
+            # PMC counters cannot be collected inside this run (rocprofv3 owns them): the file is a committed
+            # measurement of THIS library on this workload.  It names the sources it was taken on; when the
+            # kernels have changed since, the numbers are refused rather than reported stale.
+            from ebcsim import _capi
+            if tj.get("csrc_sha256") != _capi.csrc_sha256():
+                traffic_note = "profiles/traffic_%s.json was taken on other kernel sources (%s...): not reported" % (
+                    args.workload, str(tj.get("csrc_sha256"))[:12])
+            elif tj.get("envs_per_gpu") == E:
                 traffic = tj["traffic_bytes_per_step"]
                 if tj.get("SQ_INSTS_VALU_per_step"):
                     # the honest yard-stick of this launch: vector-ALU issue time.  One
@@ -536,6 +581,12 @@ def main():
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "timed_blocks": n_blocks, "block_seconds_min_max": block_spread,
+            # every env of every rank advances all its humans once per step
+            "units_per_step": int(total_humans),
+            # "measured": one rank per GPU over RCCL.  "rehearsal": a gloo job whose ranks share GPUs (or, past
+            # --rehearsal-gpu-ranks, stay on the host): the N-rank code path ran, `value` is NOT a scaling number
+            "timing": "rehearsal" if rehearsal else "measured",
+            "ranks_on_gpu": (min(world, args.rehearsal_gpu_ranks) if args.rehearsal_gpu_ranks > 0 else world) if rehearsal else world,
             "config": {"workload": "%s: %d envs/GPU x %d humans + %d static rows, ORCA + kinematics + "
                                    "collisions + reward + rotated obs (T=%d), one ebc_step (one HIP launch) per step, "
                                    "auto-reset%s" % (args.workload, E, batch.N, batch.S, env.T,
@@ -544,6 +595,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_ratio": None if traffic is None else traffic / bytes_launch, "valu": valu,
+                         "traffic_note": traffic_note,
                          "kernel": "orca_step_kernel (the one launch of a step)",
                          "launch_ms": launch_ms, "kernel_ms_event_pair": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},

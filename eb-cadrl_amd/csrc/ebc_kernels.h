@@ -144,6 +144,20 @@ __global__ __launch_bounds__(256) void pool_pref_kernel(DevState s, size_t first
   s.pool.pref[k] = make_float2(prefx, prefy);
 }
 
+// Before the pool arrays are replaced (ebc_set_scene_pool / ebc_generate_pool on a running batch): an env in the
+// middle of an episode on a pool scene keeps only that slot's INDEX for its occupancy grid.  One workgroup per env
+// copies the grid into the env's own slot e — a reset slot, never a restart source once a pool is installed — and
+// points the env at it, so the grid outlives the pool it came from.
+__global__ __launch_bounds__(256) void rehome_grid_kernel(DevState s, uint64_t *grid) {
+  const int e = blockIdx.x;
+  const int src = s.grid_scene[e];
+  if (src == e) return;
+  const size_t words = (size_t)s.G * 2;
+  for (size_t w = threadIdx.x; w < words; w += blockDim.x) grid[(size_t)e * words + w] = grid[(size_t)src * words + w];
+  __syncthreads();  // every thread has read grid_scene[e]
+  if (threadIdx.x == 0) s.grid_scene[e] = e;
+}
+
 __global__ __launch_bounds__(256) void tile_kernel(EbcParams p, DevState s) {
   const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= (size_t)s.E * s.N) return;

@@ -609,6 +609,11 @@ static int pool_impl(Handle *h, const EbcScene *sc, int stride, hipMemcpyKind ki
   if (stride < 0) return fail(EBC_ERR_INVALID, "stride");
   HIP_TRY(hipStreamSynchronize(h->stream));
   const int P = sc->n, E = s.E;
+  if (h->has_reset) {  // running episodes keep their maps: into the envs' own slots before the old slots are freed
+    hipLaunchKernelGGL(ebc::rehome_grid_kernel, dim3((unsigned)E), dim3(256), 0, h->stream, h->s, h->pool_grid_alloc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   if ((rc = alloc_pool(h, P)) != EBC_OK) return rc;  // keeps the E reset slots
   ebc::ScenePool &pl = s.pool;
   if (sc->grid) pl.grid = h->pool_grid_alloc;
@@ -1069,6 +1074,7 @@ int ebc_row_counts(void *handle, int location, long long *n_rows) {
   int rc = check_handle(handle, &h);
   if (rc) return rc;
   if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_row_counts before ebc_reset");
+  if (h->faulted) return fail(EBC_ERR_STATE, "ebc_row_counts: the handle reported a mailbox fault; ebc_reset re-arms it");
   if (!n_rows) return fail(EBC_ERR_INVALID, "null n_rows");
   long long *d = n_rows;
   Stager st{h};

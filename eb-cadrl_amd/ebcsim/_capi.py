@@ -86,6 +86,22 @@ def lib():
     return _lib
 
 
+def csrc_sha256():
+    """SHA-256 over the kernel sources the library is built from (csrc/*.h, *.hip, Makefile, the public header):
+    committed PMC measurements (profiles/traffic_*.json) name the sources they were taken on, and bench.py
+    refuses them once the kernels have changed."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_PKG, "csrc")
+    files = sorted(os.path.join(src, f) for f in os.listdir(src) if f.endswith((".h", ".hip")) or f == "Makefile")
+    files.append(os.path.join(os.path.dirname(_PKG), "include", "ebcsim.h"))
+    for path in files:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def check(rc):
     if rc != 0:
         raise EbcError(rc, lib().ebc_last_error().decode("utf-8", "replace"))

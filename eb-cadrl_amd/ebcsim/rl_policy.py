@@ -142,7 +142,31 @@ class SARL(Policy):
         return chosen
 
     def transform(self, state, env=None):
-        """multi_human_rl.py:128-149: the rotated joint state [rows, T] of the env's current state."""
-        if env is None:
-            raise ValueError("transform reads the rotated rows the env keeps for its current state")
-        return torch.from_numpy(env.observe_rotated()).to(self.device)
+        """multi_human_rl.py:128-149: the rotated joint state [rows, T].  With the env: the rows the env keeps
+        for its current state (the kernels' rotate()).  Without — the reference's one-argument call, e.g.
+        Explorer.update_memory's `target_policy.transform(state)` (rl/utils/explorer.py:162) — from `state`
+        itself on the host, float32 like the reference's tensors."""
+        if env is not None:
+            return torch.from_numpy(env.observe_rotated()).to(self.device)
+        rows = torch.Tensor([tuple(state.self_state + other) for other in state.agent_states])
+        return self.rotate(rows).to(self.device)
+
+    def rotate(self, rows):
+        """cadrl.py:236-337 on [n, 15] float32 rows (robot FullState 9 | other ObservableState 5 + type): the
+        robot-centric frame with the x axis towards the goal."""
+        sx, sy, svx, svy, sr, gx, gy, vpref, theta = (rows[:, c] for c in range(9))
+        ox, oy, ovx, ovy, orad = (rows[:, c] for c in range(9, 14))
+        ex, ey = gx - sx, gy - sy
+        ang = torch.atan2(ey, ex)
+        c, s_ = torch.cos(ang), torch.sin(ang)
+        col = lambda v: v.reshape(-1, 1)  # noqa: E731
+        heading = col(theta - ang) if self.kinematics == "unicycle" else torch.zeros_like(col(vpref))
+        rx, ry = ox - sx, oy - sy
+        parts = [torch.norm(torch.cat([col(ex), col(ey)], 1), 2, dim=1, keepdim=True), col(vpref), heading, col(sr),
+                 col(svx * c + svy * s_), col(svy * c - svx * s_),
+                 col(rx * c + ry * s_), col(ry * c - rx * s_),
+                 col(ovx * c + ovy * s_), col(ovy * c - ovx * s_), col(orad),
+                 torch.norm(torch.cat([col(sx - ox), col(sy - oy)], 1), 2, dim=1, keepdim=True), col(sr) + col(orad)]
+        if self.with_agent_type:
+            parts.append(torch.nn.functional.one_hot(rows[:, 14].long(), num_classes=self.agent_type_state_dim))
+        return torch.cat(parts, dim=1)

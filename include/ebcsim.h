@@ -224,7 +224,11 @@ int ebc_reset(void *handle, const int32_t *env_ids, const EbcScene *scene);
  * resets would dominate).  `pool` holds P host-generated scenes (same layout as for ebc_reset,
  * scene.n = P).  Env e restarts from scene cursor[e] = e mod P, and the cursor then advances by
  * `stride` (mod P), entirely on the device.  Without this call the pool is the envs' own
- * ebc_reset scenes (P = E, stride 0).  Does not touch the running episodes. */
+ * ebc_reset scenes (P = E, stride 0).  May be called again while episodes run (a smaller, larger
+ * or regenerated pool): running episodes are not touched — an env that is in the middle of an
+ * episode on a scene of the OLD pool keeps that scene's occupancy grid (copied into the env's own
+ * slot before the old pool is freed) and its static rows until its next restart; the cursors are
+ * set back to e mod P. */
 int ebc_set_scene_pool(void *handle, const EbcScene *pool, int stride);
 
 /* ---- SceneGenerator.generate_random_scene on the device (simulator/scene/scene_generator.py:330-378) ----

@@ -210,6 +210,11 @@ class OracleEnv:
             n_static=np.zeros(n, np.int32), spx=f(n, S), spy=f(n, S), sradius=f(n, S),
             grid=np.zeros((n, self.G, 2), np.uint64), robot=f(n, 9))
         if getattr(self, "pool", None) is not None:
+            # an env in the middle of an episode on a pool scene keeps only that slot's index for its map: the
+            # map moves to the env's own slot (not a restart source once a pool is installed) before the slots go
+            gs = self.a["grid_scene"]
+            self.pool["grid"][:E] = self.pool["grid"][gs]
+            gs[:] = np.arange(E, dtype=np.int32)
             for k in new:
                 new[k][:E] = self.pool[k][:E]
         else:

@@ -114,6 +114,77 @@ def check_trajectory(env, z, atol=1e-9, rot_atol=1e-5, lookahead=True):
                 assert (out[key] == out[key][0:1]).all(), msg
 
 
+def config_text_of(meta):
+    """The INI text a trajectory fixture ran with: the scenes fixture's text of the same config file plus the
+    overrides recorded in the fixture's meta."""
+    import configparser
+    import io
+    zs = load("scenes")
+    for k in range(int(zs["n"])):
+        m = json.loads(str(zs["meta_%d" % k]))
+        if m["config"] == meta["config"]:
+            cfg = configparser.RawConfigParser()
+            cfg.read_string(m["config_text"])
+            for key, val in meta["overrides"].items():
+                sec, opt = key.split(".")
+                if sec in ("adults", "bicycles", "children") and opt == "policy":
+                    continue
+                cfg.set(sec, opt, str(val))
+            buf = io.StringIO()
+            cfg.write(buf)
+            return buf.getvalue()
+    raise KeyError(meta["config"])
+
+
+def pool_reinstall_run(envs, E=24, steps=(60, 40, 60)):
+    """ebc_set_scene_pool on a RUNNING batch (walls: every scene has its own occupancy grid): install 3 E scenes,
+    step until envs have restarted from them, replace the pool by a SMALLER one (E / 2 scenes), keep stepping, then
+    by a larger one.  Every env of `envs` gets the same calls; yields (phase, step, [outputs per env]) and checks,
+    on envs[-1] after each re-installation, that every env still collides against the map of the scene whose
+    static rows it holds — the env must not follow the pool's slots."""
+    import configparser
+    from ebcsim import scene as ebc_scene
+    z = load("traj_n10_walls_t17_orcasub")
+    meta = json.loads(str(z["meta"]))
+    params = params_of(z)
+    params.time_limit = 4  # short episodes: many restarts
+    cfg = configparser.RawConfigParser()
+    cfg.read_string(config_text_of(meta))
+    sc = ebc_scene.SceneConfig.from_config(cfg)
+    gen = lambda seeds: [ebc_scene.generate_scene(sc, int(s)) for s in seeds]  # noqa: E731
+    all_scenes = {}
+
+    def batch(seeds, N=None, S=None):
+        b = ebc_scene.SceneBatch.from_scenes(gen(seeds), N, S)
+        for c in range(b.n):
+            all_scenes[b.spx[c].tobytes() + b.spy[c].tobytes()] = b.grid[c].copy()
+        return b
+    first = batch(range(7000, 7000 + E), None, 12)
+    N, S = first.N, first.S
+    pools = [batch(range(7100, 7100 + 3 * E), N, S), batch(range(7300, 7300 + E // 2), N, S),
+             batch(range(7400, 7400 + 5 * E), N, S)]
+    made = [mk(params, E, N, S) for mk in envs]
+    for env in made:
+        env.reset(first)
+    probe = made[-1]
+    restarts = 0
+    for phase, pool in enumerate(pools):
+        for env in made:
+            env.set_scene_pool(pool, stride=E)
+        if hasattr(probe, "pool"):  # the oracle: white box
+            gs = probe.a["grid_scene"]
+            for e in range(E):
+                key = probe.a["spx"][e].tobytes() + probe.a["spy"][e].tobytes()
+                np.testing.assert_array_equal(probe.pool["grid"][gs[e]], all_scenes[key], err_msg="phase %d env %d" % (phase, e))
+        for t in range(steps[phase]):
+            outs = [env.step(human_policy=_abi.HUMAN_ORCA, robot_policy=_abi.ROBOT_LINEAR, flags=_abi.FLAG_AUTO_RESET)
+                    for env in made]
+            restarts += int(outs[-1]["done"].sum())
+            yield phase, t, outs
+    assert restarts > 4 * E
+    yield -1, 0, [env.get_state() for env in made]
+
+
 class CpuDeviceEnv(object):
     """The *_device call surface of ebcsim.batched.BatchedEnv on CPU torch tensors, computed by the
     oracle: lets the trainer's schedule (ebcsim/train.py: collect, collect_il, run_training — host

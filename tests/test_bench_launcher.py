@@ -8,6 +8,8 @@ import os
 import sys
 import textwrap
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
@@ -43,6 +45,32 @@ def test_launch_ranks_reports_a_failed_rank():
     assert rc != 0
 
 
+HANG_PROGRAM = textwrap.dedent("""
+    import os, sys, time
+    if int(os.environ["RANK"]) == int(sys.argv[1]):
+        sys.exit(7)          # e.g. a HIP error or a reported mailbox fault
+    time.sleep(600)          # the survivors: in a barrier that never completes
+""")
+
+
+@pytest.mark.parametrize("dead", [0, 1, 2])
+def test_a_dead_rank_ends_the_job_promptly(dead):
+    """Whichever rank dies first, the parent returns its code at once and leaves no survivor behind."""
+    import time
+    import bench
+    t0 = time.monotonic()
+    rc, out = bench.launch_ranks(3, [sys.executable, "-c", HANG_PROGRAM, str(dead)], timeout=300)
+    assert rc == 7 and time.monotonic() - t0 < 30
+
+
+def test_job_timeout_is_finite():
+    import time
+    import bench
+    t0 = time.monotonic()
+    rc, out = bench.launch_ranks(2, [sys.executable, "-c", HANG_PROGRAM, "-1"], timeout=3)
+    assert rc == 124 and time.monotonic() - t0 < 30
+
+
 def test_parent_does_not_touch_the_gpu_before_spawning():
     """The self-launch branch sits before any torch import in main(): the parent must stay free of HIP state
     (a process that initialised the GPU must not start replacing itself, and need not hold a context)."""
@@ -52,7 +80,11 @@ def test_parent_does_not_touch_the_gpu_before_spawning():
     assert "os.exec" not in src
 
 
-import pytest  # noqa: E402
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
 
 
 @pytest.mark.gpu
@@ -61,7 +93,7 @@ def test_bench_rank_through_rccl_on_one_rank():
     MAX all-reduce of the block times and job_rate's reductions forced through the backend
     (EBCSIM_FORCE_COLLECTIVES=1) — the calls an N-GPU run makes, on device tensors."""
     import subprocess
-    env = dict(os.environ, EBCSIM_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", RANK="0",
+    env = dict(os.environ, EBCSIM_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0",
                LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "5",
                         "--no-also", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
@@ -72,3 +104,25 @@ def test_bench_rank_through_rccl_on_one_rank():
                             "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
     ref = json.loads(plain.stdout.strip().splitlines()[-1])
     assert abs(line["value"] / ref["value"] - 1) < 0.2  # the same job with and without the group
+
+
+@pytest.mark.gpu
+def test_eight_rank_rehearsal_of_config4_on_one_gpu():
+    """BASELINE config 4 in its 8-rank FORM on the one GPU there is: `bench.py --gpus 8 --workload cfg4` starts eight
+    rank processes (gloo process group, ranks share the device), every rank builds ITS env slice of 16384 x 5 and the
+    job prints one line.  No scaling number can come out of ranks that share a GPU — the line says so
+    ("timing": "rehearsal"); the measured curve is the driver's, on an 8-GPU node."""
+    import subprocess
+    env = dict(os.environ, EBCSIM_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    # 6 ranks at most may share the card on the GPU box (process guard): the rehearsal keeps the 8-rank bookkeeping
+    # (slices, seeds, reductions) and is told to put at most 4 ranks on the device at a time
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "cfg4", "--steps", "5",
+                        "--warmup", "2", "--no-cpu-baseline", "--no-also", "--rehearsal-gpu-ranks", "4"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["config"]["envs_per_gpu"] == 16384 and line["timing"] == "rehearsal"
+    assert line["roofline"]["achieved"] > 0 and line["scaling"] == "weak"
+    assert line["units_per_step"] == 8 * 16384 * 5

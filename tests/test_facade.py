@@ -255,3 +255,28 @@ def test_imitation_learning_episode_cpu_backend(name):
 @pytest.mark.parametrize("name", ["traj_a5_il_orcasub", "traj_n10_walls_il_orcasub"])
 def test_imitation_learning_episode_gpu(name):
     _il_episode(name, None)
+
+
+def test_policy_transform_without_env_is_the_reference_rotate():
+    """`policy.transform(state)` with ONE argument (rl/utils/explorer.py:162 calls the target policy that way): the
+    host rotate equals the reference's rotate() goldens (cadrl.py:236-337; T = 13, 17 and the unicycle frame) and the
+    rows the env keeps for the same state."""
+    import torch
+    from ebcsim.rl_policy import SARL
+    from ebcsim.state import FullState, JointState, ObservableState
+    z = load("rotate")
+    for v in range(int(z["n"])):
+        pol = SARL()
+        pol.with_agent_type = bool(z["with_agent_type_%d" % v])
+        pol.agent_type_state_dim = 4 if pol.with_agent_type else 0
+        pol.kinematics = "unicycle" if int(z["unicycle_%d" % v]) else "holonomic"
+        pol.device = torch.device("cpu")
+        rows = z["in_%d" % v]
+        got = pol.rotate(torch.Tensor(rows.tolist())).numpy()
+        np.testing.assert_allclose(got, z["out_%d" % v], atol=2e-6, rtol=2e-6)
+        # through transform(): a JointState of one robot row and a few "others"
+        r = rows[0]
+        js = JointState(FullState(*[float(x) for x in r[:9]]),
+                        [ObservableState(*[float(x) for x in q[9:14]], int(q[14])) for q in rows[:5]])
+        want = pol.rotate(torch.Tensor([list(r[:9]) + list(q[9:15]) for q in rows[:5]]))
+        np.testing.assert_array_equal(pol.transform(js).numpy(), want.numpy())

@@ -645,6 +645,20 @@ def test_scene_pool_auto_reset():
     np.testing.assert_array_equal(ob_g, ob_o)
 
 
+def test_scene_pool_reinstalled_on_running_episodes():
+    """ebc_set_scene_pool while envs are in the middle of episodes on scenes of the old pool — what run_training does
+    every few steps with device-generated scenes: a smaller pool, then a larger one; every output every step against
+    the oracle (whose own map bookkeeping is checked in test_oracle_golden.py)."""
+    from helpers import pool_reinstall_run
+    from oracle import oracle
+    for phase, t, (og, oo) in pool_reinstall_run([_env, lambda p, E, N, S: oracle.OracleEnv(p, E, N, S)]):
+        if phase >= 0:
+            _compare_step(og, oo, "pool %d step %d" % (phase, t))
+        else:
+            for k in og:
+                np.testing.assert_allclose(og[k], oo[k], atol=1e-9, rtol=0, err_msg=k)
+
+
 @pytest.mark.parametrize("fixture,E,steps,safety", [
     ("traj_a5_il_orcasub", 200, 60, 0.15),          # 5 rows: 5-lane groups
     ("traj_n10_walls_il_orcasub", 150, 90, 0.15),   # 18 rows (ragged static rows): 21-lane groups

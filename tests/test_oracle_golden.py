@@ -247,6 +247,16 @@ def test_scene_pool_semantics_cpu():
             np.testing.assert_array_equal(env2.get_state()["px"], b.px)
 
 
+def test_scene_pool_reinstalled_on_running_episodes_cpu():
+    """A running env keeps the map of the scene it is on when the pool is replaced (smaller, then larger)."""
+    from helpers import pool_reinstall_run
+    kinds = set()
+    for phase, t, outs in pool_reinstall_run([lambda p, E, N, S: oracle.OracleEnv(p, E, N, S)]):
+        if phase >= 0:
+            kinds.update(outs[0]["info"].tolist())
+    assert _abi.INFO_COLLISION_OBSTACLE in kinds  # the maps matter in this workload
+
+
 def test_threaded_oracle_equals_scalar():
     """bench.py's all-cores CPU baseline splits orc_step's env loop over OpenMP threads: same
     results as the one-thread port, every output and the state, through restarts."""

@@ -59,13 +59,20 @@ def main():
             dist.barrier()
         return time.perf_counter()
 
-    # stage timings: the schedule once with the IL stage only, then the RL rounds
+    # stage timings: the IL rollouts alone (after one untimed warm-up call: first launches, allocations, clocks;
+    # always on the HOST-generated batch, whatever --device-scenes says: the il_* fields are labelled so), then
+    # the whole schedule
+    mem = DeviceReplay(args.il_steps * args.envs, env.R, env.T, dev)
+    collect_il(env, mem, min(args.il_steps, 20), 0.9, 0.15)
+    del mem
+    env.reset(batch)
     t0 = sync()
     mem = DeviceReplay(args.il_steps * args.envs, env.R, env.T, dev)
     stored, episodes = collect_il(env, mem, args.il_steps, 0.9, 0.15)
     t1 = sync()
     times["il_rollout_s"] = t1 - t0
     times["il_env_steps_per_s"] = args.il_steps * args.envs * world / (t1 - t0)
+    times["il_fields"] = "il_* measured on the host-generated batch after a 20-step warm-up call (not on device-generated scenes)"
     del mem
     env.reset(batch)
     t0 = sync()
