@@ -284,8 +284,20 @@ __global__ __launch_bounds__(EBC_WAVE) void orca_kernel(EbcParams p, DevState s)
 // group per env; lane j = row j of the observation the policy is given — the humans (env.py:381-382)
 // then the static obstacles as pedestrians (env.py:457-458, velocity 0) —, every radius + 0.01 +
 // safety_space as orca.py:116-126 hands it to rvo2, the robot's maxSpeed = v_pref.  -> act[E][2].
+// The demonstrator's persistent rvo2 simulator (simulator/policy/orca.py:96-133): the policy object keeps ONE simulator
+// for all its calls and rebuilds it only when the number of agents changes; otherwise it updates positions and
+// velocities — the rows' radii (+ 0.01 + safety_space), the robot's radius and its maxSpeed stay those of the call that
+// built it, across env.reset() too (rl/train.py:130-133 makes one il_policy for the whole imitation-learning stage).
+// Per env: rows[e] = rows of its simulator (-1: none yet), radius[e][N + S] and self[e] = {radius, maxSpeed} as rvo2
+// holds them.  rows == nullptr: no persistent simulator (every call from the current state).
+struct RobotSim {
+  int *rows;
+  float *radius;
+  float2 *self;
+};
+
 template <int GS>
-__global__ __launch_bounds__(EBC_WAVE) void orca_robot_kernel(EbcParams p, DevState s, double safety_space, double *act) {
+__global__ __launch_bounds__(EBC_WAVE) void orca_robot_kernel(EbcParams p, DevState s, double safety_space, double *act, RobotSim sim) {
   using L = OrcaLds<GS>;
   constexpr int EPW = EBC_WAVE / GS;
   __shared__ __align__(16) unsigned char scratch[L::BYTES];
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(EBC_WAVE) void orca_robot_kernel(EbcParams p, DevSt
   const int ns = (e_ok && S) ? s.n_static[ee] : 0;
   const double *rb = s.robot + ee * 9;
   const float posx = (float)rb[0], posy = (float)rb[1], velx = (float)rb[2], vely = (float)rb[3];
-  const float radius = (float)(rb[4] + 0.01 + safety_space), maxSpeed = (float)rb[7];
+  float radius = (float)(rb[4] + 0.01 + safety_space), maxSpeed = (float)rb[7];
   float prefx, prefy;
   orca_pref_velocity(rb[0], rb[1], rb[5], rb[6], prefx, prefy);
   const bool valid = e_ok && j < n + ns;
@@ -319,6 +331,23 @@ __global__ __launch_bounds__(EBC_WAVE) void orca_robot_kernel(EbcParams p, DevSt
     opx = (float)s.spx[q];
     opy = (float)s.spy[q];
     orad = (float)(s.sradius[q] + 0.01 + safety_space);
+  }
+  if (sim.rows && e_ok) {
+    // every lane of the group reads the simulator's row count before lane 0 of the group replaces it (one wave)
+    const bool rebuild = sim.rows[ee] != n + ns;  // sim is None, or getNumAgents() != len(agent_states) + 1
+    const size_t q = ee * (size_t)(N + S) + j;
+    if (rebuild) {
+      if (valid) sim.radius[q] = orad;
+      if (j == 0) {
+        sim.self[ee] = make_float2(radius, maxSpeed);
+        sim.rows[ee] = n + ns;
+      }
+    } else {
+      if (valid) orad = sim.radius[q];
+      const float2 me = sim.self[ee];
+      radius = me.x;
+      maxSpeed = me.y;
+    }
   }
   float ox, oy;
   orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy, ovx, ovy,

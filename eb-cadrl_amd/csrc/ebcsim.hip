@@ -45,6 +45,8 @@ struct Handle {
   hipStream_t stream = nullptr;
   bool has_reset = false;
   double *act_scratch = nullptr;  // ebc_step_k: the ORCA robot's action when the caller keeps none
+  int *robot_sim_rows = nullptr;
+  ebc::RobotSim robot_sim = {nullptr, nullptr, nullptr};  // ebc_robot_orca_sim: the demonstrator's persistent rvo2 simulators
   bool faulted = false;  // a mailbox wait timed out and was reported: only ebc_reset re-arms the handle
   int orca_gs = 16;  // lanes per human of the ORCA waves
   unsigned epoch = 0;  // fused ORCA steps launched so far (StepGrid::epoch)
@@ -799,7 +801,7 @@ int launch_robot_orca(Handle *h, double safety_space, double *d_act) {
     if (g >= others) { gs = g; break; }
   const int epw = EBC_WAVE / gs;
   const unsigned blocks = (unsigned)((h->s.E + epw - 1) / epw);
-#define RK_(GS) hipLaunchKernelGGL((ebc::orca_robot_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, safety_space, d_act)
+#define RK_(GS) hipLaunchKernelGGL((ebc::orca_robot_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, safety_space, d_act, h->robot_sim)
   switch (gs) {
     case 2: RK_(2); break;
     case 3: RK_(3); break;
@@ -858,6 +860,49 @@ int ebc_robot_orca(void *handle, double safety_space, int location, double *acti
   }
   if ((rc = launch_robot_orca(h, safety_space, d_act)) != EBC_OK) return rc;
   if (location != EBC_DEVICE) return st.finish();
+  return EBC_OK;
+}
+
+int ebc_robot_orca_sim(void *handle, int enable) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const size_t E = h->s.E, R = (size_t)h->s.N + h->s.S;
+  if (!enable) {  // the arrays stay allocated (freed with the handle); the kernels get no simulator
+    h->robot_sim.rows = nullptr;
+    return EBC_OK;
+  }
+  if (!h->robot_sim.radius) {
+    int *rows = nullptr;
+    if ((rc = dev_alloc(h, &rows, E)) != EBC_OK) return rc;
+    if ((rc = dev_alloc(h, &h->robot_sim.radius, E * R)) != EBC_OK) return rc;
+    if ((rc = dev_alloc(h, &h->robot_sim.self, E)) != EBC_OK) return rc;
+    h->robot_sim_rows = rows;
+  }
+  h->robot_sim.rows = h->robot_sim_rows;
+  HIP_TRY(hipMemset(h->robot_sim.rows, 0xff, E * sizeof(int)));  // -1: no simulator yet (a fresh policy object)
+  return EBC_OK;
+}
+
+int ebc_robot_orca_sim_state(void *handle, int location, int set, int32_t *rows, float *radius, float *self) {
+  Handle *h;
+  int rc = check_handle(handle, &h);
+  if (rc) return rc;
+  if (!h->robot_sim.rows) return fail(EBC_ERR_STATE, "ebc_robot_orca_sim_state: no persistent simulator (ebc_robot_orca_sim)");
+  if (!rows || !radius || !self) return fail(EBC_ERR_INVALID, "null argument");
+  const size_t E = h->s.E, R = (size_t)h->s.N + h->s.S;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const hipMemcpyKind kind = location == EBC_DEVICE ? hipMemcpyDeviceToDevice : (set ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost);
+  if (set) {
+    HIP_TRY(hipMemcpy(h->robot_sim.rows, rows, E * sizeof(int), kind));
+    HIP_TRY(hipMemcpy(h->robot_sim.radius, radius, E * R * sizeof(float), kind));
+    HIP_TRY(hipMemcpy(h->robot_sim.self, self, E * 2 * sizeof(float), kind));
+  } else {
+    HIP_TRY(hipMemcpy(rows, h->robot_sim.rows, E * sizeof(int), kind));
+    HIP_TRY(hipMemcpy(radius, h->robot_sim.radius, E * R * sizeof(float), kind));
+    HIP_TRY(hipMemcpy(self, h->robot_sim.self, E * 2 * sizeof(float), kind));
+  }
   return EBC_OK;
 }
 

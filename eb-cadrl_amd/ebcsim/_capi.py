@@ -25,6 +25,8 @@ SYMBOLS = {
     "ebc_set_human_actions": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ebc_observe": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ebc_robot_orca": (C.c_int, [C.c_void_p, C.c_double, C.c_int, C.c_void_p]),
+    "ebc_robot_orca_sim": (C.c_int, [C.c_void_p, C.c_int]),
+    "ebc_robot_orca_sim_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ebc_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_lookahead": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ebc_step_k": (C.c_int, [C.c_void_p, C.c_void_p]),

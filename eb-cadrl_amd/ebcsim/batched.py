@@ -237,6 +237,24 @@ class BatchedEnv:
         _capi.check(self._L.ebc_robot_orca(self._h, float(safety_space), _abi.HOST, act.ctypes.data))
         return act
 
+    def robot_orca_sim(self, enable=True):
+        """The demonstrator's persistent rvo2 simulator (simulator/policy/orca.py:96-133), one per env, all "not built
+        yet" (a fresh policy object); enable=False: every robot_orca call from the current state alone."""
+        _capi.check(self._L.ebc_robot_orca_sim(self._h, 1 if enable else 0))
+        self._robot_sim = bool(enable)
+
+    def robot_orca_sim_state(self, state=None):
+        """Read (state None) or replace the simulators: dict(rows int32 [E], radius float32 [E, R], self float32 [E, 2])."""
+        if state is not None and not getattr(self, "_robot_sim", False):
+            self.robot_orca_sim(True)
+        rows = np.zeros(self.E, np.int32) if state is None else np.ascontiguousarray(state["rows"], np.int32).reshape(self.E)
+        rad = (np.zeros((self.E, self.R), np.float32) if state is None
+               else np.ascontiguousarray(state["radius"], np.float32).reshape(self.E, self.R))
+        me = np.zeros((self.E, 2), np.float32) if state is None else np.ascontiguousarray(state["self"], np.float32).reshape(self.E, 2)
+        _capi.check(self._L.ebc_robot_orca_sim_state(self._h, _abi.HOST, 0 if state is None else 1, rows.ctypes.data,
+                                                     rad.ctypes.data, me.ctypes.data))
+        return dict(rows=rows, radius=rad, self=me)
+
     def robot_orca_device(self, actions, safety_space=0.0):
         """The same into a torch CUDA tensor float64 [E, 2] (enqueued on the handle's stream)."""
         if actions.dtype.itemsize != 8 or actions.numel() != self.E * 2 or not actions.is_contiguous():

@@ -88,17 +88,27 @@ class ORCA(DeviceHumanPolicy):
         self.neighbor_dist, self.max_neighbors = 10, 10  # orca.py:64-69: what the kernels use (EbcParams)
         self.time_horizon = self.time_horizon_obst = 5
         self.radius, self.max_speed = 0.3, 200
+        self.sim = None  # orca.py:70: this object's rvo2 simulator (rows, the radii and maxSpeed it was built with)
 
     def predict(self, state, env=None):
         """`state` must be the env's current joint state (Robot.act builds it from the observation the
-        env has just returned): the arithmetic reads the device-resident copy of it."""
+        env has just returned): the arithmetic reads the device-resident copy of it.  Like the reference's
+        object this one keeps its simulator from call to call (orca.py:96-133): it is rebuilt only when the
+        number of agents changes, so between rebuilds the radii (+ 0.01 + safety_space) and the robot's maxSpeed
+        are those of the call that built it — also across env.reset()."""
         if env is None or getattr(env, "_backend", None) is None:
             raise ValueError("ORCA as a robot policy needs the env it acts in (robot.act(ob, env=env)) after reset()")
         s = state.self_state
         rb = env._backend.get_state()["robot"][0]
         if (s.px, s.py, s.gx, s.gy) != (rb[0], rb[1], rb[5], rb[6]):
             raise ValueError("ORCA.predict: the state passed in is not the env's current state")
-        vx, vy = env._backend.robot_orca(self.safety_space)[0]
+        be = env._backend
+        if self.sim is not None and self.sim["radius"].shape[1] == be.R:
+            be.robot_orca_sim_state(self.sim)   # this object's simulator onto the handle that serves the call
+        else:
+            be.robot_orca_sim(True)             # none yet, or another number of rows: built from this state
+        vx, vy = be.robot_orca(self.safety_space)[0]
+        self.sim = be.robot_orca_sim_state()
         self.last_state = state
         return ActionXY(float(vx), float(vy))
 

@@ -370,13 +370,20 @@ def collect(env, policy, target_net, memory, steps, gamma, epsilon=0.0, generato
     return total / steps
 
 
-def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HUMAN_ORCA):
+def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HUMAN_ORCA, persistent_sim=True):
     """The imitation-learning stage's rollouts (rl/train.py:124-133, explorer.py:33-92 with
     imitation_learning=True): the robot of every env of the rank's slice on ORCA (ebc_robot_orca ->
     ebc_step, auto-reset) for `steps` steps; the states of every episode that ended inside the window in
     ReachGoal or a collision (explorer.py:82-92) go to `memory` with their discounted returns.  Returns
-    (steps stored, episodes ended)."""
+    (steps stored, episodes ended).
+    Demonstrator semantics (persistent_sim=True, the reference's): every env is ONE il_policy object playing its
+    episodes one after the other, as rl/train.py:130-133 builds one for the whole stage — its rvo2 simulator is
+    built at the env's first step of this call and again whenever the row count of its scene changes, and in between
+    keeps the radii / maxSpeed it was built with (simulator/policy/orca.py:96-133), across restarts too: an env's
+    episode sequence equals the reference's serial sequence on the same scenes (tests: il_persistent_* goldens).
+    persistent_sim=False: the demonstrator sees every state's own radii (a fresh policy object per step)."""
     E, R, T = env.E, env.R, env.T
+    env.robot_orca_sim(bool(persistent_sim))
     v_pref = float(env.get_state()["robot"][0, 7])
     gamma_bar = gamma ** (env.params.time_step * v_pref)
     ragged = bool(getattr(env, "ragged", False))

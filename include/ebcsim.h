@@ -299,6 +299,22 @@ int ebc_observe(void *handle, int location, double *ob, float *obs_rotated);
  * N + S <= 32. */
 int ebc_robot_orca(void *handle, double safety_space, int location, double *action);
 
+/* The demonstrator's PERSISTENT rvo2 simulator (simulator/policy/orca.py:96-133).  The reference's ORCA policy object
+ * keeps one simulator for all its predict() calls and rebuilds it only when the number of agents changes
+ * (orca.py:96-101); otherwise it updates positions and velocities only (:129-133), so the rows' radii
+ * (+ 0.01 + safety_space), the robot's radius and its maxSpeed stay those of the call that BUILT the simulator — also
+ * across env.reset(): rl/train.py:130-133 makes ONE il_policy for every imitation-learning episode, and with
+ * randomize_attributes = true episodes 2... run on the radii of the episode that built it.
+ * enable != 0: from now on ebc_robot_orca and EBC_ROBOT_ORCA (ebc_step_k) of this handle behave like that, one
+ * simulator per env (an env = one policy object playing its episodes one after the other), all of them "not built
+ * yet" (= a fresh policy object; call it again for the next one).  enable == 0 (the default): every call works from
+ * the current state alone (= a fresh policy object per call).  ebc_reset and restarts do not touch the simulators. */
+int ebc_robot_orca_sim(void *handle, int enable);
+/* Read (set == 0) or replace (set != 0) the simulators: rows [E] (number of agents besides the robot, -1 = not built),
+ * radius [E][N + S] (float, as rvo2 holds them: row j of the observation), self [E][2] = {radius, maxSpeed}.  The
+ * single-env facade keeps a policy object's simulator in the object and hands it to whichever handle serves it. */
+int ebc_robot_orca_sim_state(void *handle, int location, int set, int32_t *rows, float *radius, float *self);
+
 /* One env.step for every env (simulator/env.py:388-466), enqueued on the handle's stream.  With
  * EBC_HUMAN_ORCA it is ONE kernel launch whose arguments change from call to call (the robot state
  * is double-buffered and a launch counter travels with the launch): call it once per step; do not

@@ -90,6 +90,11 @@ void orc_propagate_robot(const double *robot, int kinematics, double a0, double 
 int orc_observe(const EbcParams *p, const OrcState *s, double *ob, float *obs_rotated);
 int orc_step(const EbcParams *p, OrcState *s, const EbcStepArgs *a);
 int orc_lookahead(const EbcParams *p, OrcState *s, const EbcLookaheadArgs *a);
+/* ORCA.predict with the robot as the agent: stateless, and with the policy object's persistent rvo2 simulator
+ * (sim_rows [E] (-1 = none yet), sim_radius [E][N + S], sim_self [E][2]) */
+int orc_robot_orca(const EbcParams *p, const OrcState *s, double safety_space, double *action);
+int orc_robot_orca_sim(const EbcParams *p, const OrcState *s, double safety_space, int32_t *sim_rows,
+                       float *sim_radius, float *sim_self, double *action);
 
 #ifdef __cplusplus
 }

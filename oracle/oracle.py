@@ -63,6 +63,8 @@ def lib():
         L.orc_lookahead.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_robot_orca.restype = i
         L.orc_robot_orca.argtypes = [C.c_void_p, C.c_void_p, d, C.c_void_p]
+        L.orc_robot_orca_sim.restype = i
+        L.orc_robot_orca_sim.argtypes = [C.c_void_p, C.c_void_p, d, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_set_threads.restype = i
         L.orc_set_threads.argtypes = [i]
         _LIB = L
@@ -334,11 +336,33 @@ class OracleEnv:
                           obs.ctypes.data)
         return ob, obs
 
+    def robot_orca_sim(self, enable=True):
+        """The checker's ebc_robot_orca_sim: a fresh persistent simulator per env (no simulator yet), or none."""
+        if enable:
+            self._sim = dict(rows=np.full(self.E, -1, np.int32), radius=np.zeros((self.E, self.R), np.float32),
+                             self=np.zeros((self.E, 2), np.float32))
+        else:
+            self._sim = None
+
+    def robot_orca_sim_state(self, state=None):
+        """get (state None) / set the simulators: dict(rows [E], radius [E, R], self [E, 2])"""
+        if state is None:
+            return {k: v.copy() for k, v in self._sim.items()}
+        self.robot_orca_sim(True)
+        for k in self._sim:
+            self._sim[k][...] = state[k]
+
     def robot_orca(self, safety_space=0.0):
-        """ORCA.predict for the robot of every env (orc_robot_orca) -> actions [E, 2]."""
+        """ORCA.predict for the robot of every env (orc_robot_orca / orc_robot_orca_sim) -> actions [E, 2]."""
         act = np.zeros((self.E, 2))
-        rc = lib().orc_robot_orca(C.addressof(self.params), C.addressof(self._state()),
-                                  float(safety_space), act.ctypes.data)
+        sim = getattr(self, "_sim", None)
+        if sim is not None:
+            rc = lib().orc_robot_orca_sim(C.addressof(self.params), C.addressof(self._state()), float(safety_space),
+                                          sim["rows"].ctypes.data, sim["radius"].ctypes.data, sim["self"].ctypes.data,
+                                          act.ctypes.data)
+        else:
+            rc = lib().orc_robot_orca(C.addressof(self.params), C.addressof(self._state()),
+                                      float(safety_space), act.ctypes.data)
         if rc:
             raise RuntimeError("orc_robot_orca failed: %d" % rc)
         return act

@@ -617,6 +617,81 @@ def gen_il(ref):
                    il_safety_space=0.15, stop_when_done=True)
 
 
+def gen_il_persistent(ref):
+    """Consecutive imitation-learning episodes on ONE il_policy, by the reference's own loop
+    (Explorer.run_k_episodes(k, "train", update_memory=True, imitation_learning=True), rl/train.py:130-133): the
+    ORCA policy object keeps its rvo2 simulator from episode to episode and rebuilds it only when the number of
+    agents changes (simulator/policy/orca.py:96-133), so with randomize_attributes = true the later episodes run on
+    the radii (and the robot's maxSpeed) of the episode that built the simulator.  rvo2 is the oracle-substituted
+    shim (it keeps what addAgent was given, like the real one).  Two fixtures: a constant number of rows
+    (circles), and walls of random length (the row count changes in between)."""
+    import torch
+    from rl.utils.explorer import Explorer
+    from rl.utils.memory import ReplayMemory
+    from simulator.utils.test_utils import configure_env_policy_robot
+    RVO2_MODE["substitute"] = True
+    const_rows, wall_rows = dict(N10), dict(N10)
+    const_rows.update({("map", "num_walls"): 0, ("map", "num_circles"): 3})
+    wall_rows.update({("map", "num_walls"): 3, ("map", "min_wall_length"): 2, ("map", "max_wall_length"): 6})
+    runs = [("il_persistent_const_rows", const_rows, 4), ("il_persistent_wall_rows", wall_rows, 5)]
+    for name, ov, episodes in runs:
+        text = cfg_text(os.path.join(ref, BIG), ov)
+        cfg = parsed(text)
+        pol_path = os.path.join(ref, P17)
+        env, pol, robot = make_env(ref, text, pol_path, policy="orca", phase="train")
+        pol.multiagent_training = True   # rl/train.py:131 (the SARL configs say true)
+        pol.safety_space = 0.15          # rl/train.py:126-132, configs/train_configs/*.config
+        sarl = make_sarl(ref, P17)
+        sarl.time_step = cfg.getfloat("env", "time_step")
+        memory = ReplayMemory(100000)
+        ex = Explorer(env, robot, "cpu", memory, IL_GAMMA, target_policy=sarl)
+        eps = []
+        real_reset, real_step, real_act = env.reset, env.step, robot.act
+
+        def reset(*a, **k):
+            ret = real_reset(*a, **k)
+            eps.append(dict(init=scene_arrays(env), action=[], reward=[], info=[], rows=len(ret[0]),
+                            sim_rebuilt=None))
+            return ret
+
+        def act(ob, **k):
+            before = pol.sim  # the object itself: an id() can be reused by the simulator that replaces it
+            a = real_act(ob, **k)
+            if not eps[-1]["action"]:
+                eps[-1]["sim_rebuilt"] = pol.sim is not before
+            eps[-1]["action"].append([a[0], a[1]])
+            return a
+
+        def step(action, *a, **k):
+            ret = real_step(action, *a, **k)
+            eps[-1]["reward"].append(ret[2])
+            eps[-1]["info"].append(info_code(ret[4]))
+            return ret
+        env.reset, env.step, robot.act = reset, step, act
+        ex.run_k_episodes(episodes, "train", update_memory=True, imitation_learning=True)
+        env.reset, env.step, robot.act = real_reset, real_step, real_act
+        params = ebc_config.params_from_config(cfg, parsed(open(pol_path).read()))
+        out = {"n_episodes": np.array(len(eps)), "il_gamma": np.array(IL_GAMMA), "robot_v_pref": np.array(robot.v_pref),
+               "safety_space": np.array(0.15), "params": jdump(ebc_config.params_to_dict(params)),
+               "rows": np.array([e["rows"] for e in eps]), "sim_rebuilt": np.array([bool(e["sim_rebuilt"]) for e in eps]),
+               "meta": jdump({"config": BIG, "overrides": {"%s.%s" % k: v for k, v in ov.items()}, "policy_config": P17})}
+        for k, e in enumerate(eps):
+            for key, v in e["init"].items():
+                out["init%d_%s" % (k, key)] = v
+            out["action%d" % k] = np.array(e["action"])
+            out["reward%d" % k] = np.array(e["reward"], float)
+            out["info%d" % k] = np.array(e["info"])
+        # what the reference's Explorer put into the replay memory over all episodes (success / collision ones only)
+        out["il_state_rows"] = np.array([m[0].shape[0] for m in memory.memory])
+        out["il_state"] = np.concatenate([m[0].numpy() for m in memory.memory], 0)
+        out["il_value"] = np.array([float(m[1][0]) for m in memory.memory])
+        save(name, **out)
+        print("  %s: rows per episode %s, simulator rebuilt %s, steps %s, final infos %s" % (
+            name, out["rows"].tolist(), out["sim_rebuilt"].tolist(), [len(e["action"]) for e in eps],
+            [e["info"][-1] for e in eps]))
+    RVO2_MODE["substitute"] = False
+
+
 # --------------------------------------------- (viii) the reference's known-answer scenes
 KNOWN = [
     ("configs/test_configs/test_env_configs/env_adults_5_bikes_5_static_5.config",
@@ -839,7 +914,7 @@ def gen_local_map(ref):
 
 GENERATORS = {"collisions": gen_collisions, "reward": gen_reward, "grid": gen_grid,
               "rotate": gen_rotate, "action_space": gen_action_space, "scenes": gen_scenes,
-              "trajectories": gen_trajectories, "il": gen_il, "known": gen_known_answers, "sarl": gen_sarl, "sarl_rl": gen_sarl_rl_memory, "trainer": gen_trainer_steps, "sarl_configs": gen_sarl_configs,
+              "trajectories": gen_trajectories, "il": gen_il, "il_persistent": gen_il_persistent, "known": gen_known_answers, "sarl": gen_sarl, "sarl_rl": gen_sarl_rl_memory, "trainer": gen_trainer_steps, "sarl_configs": gen_sarl_configs,
               "local_map": gen_local_map}
 
 

@@ -275,6 +275,51 @@ class CpuDeviceEnv(object):
             t.copy_(torch.from_numpy(out[k]))
         self.steps += K
 
+    def robot_orca_sim(self, enable=True):
+        self._o.robot_orca_sim(enable)
+
     def robot_orca_device(self, actions, safety_space=0.0):
         import torch
         actions.copy_(torch.from_numpy(self._o.robot_orca(safety_space)))
+
+
+def il_persistent_episodes(name, copies=1):
+    """(z, params, N, S, [SceneBatch per episode]) of an il_persistent_* fixture."""
+    z = load(name)
+    K = int(z["n_episodes"])
+    N = max(len(z["init%d_px" % k]) for k in range(K))
+    S = max(len(z["init%d_static" % k].reshape(-1, 3)) for k in range(K))
+    return z, params_of(z), N, S, [batch_from_init(z, prefix="init%d_" % k, copies=copies, max_humans=N, max_static=S)
+                                    for k in range(K)]
+
+
+def check_il_persistent(make_env, name, copies=1):
+    """Consecutive imitation-learning episodes on ONE ORCA policy object (the reference's Explorer.run_k_episodes on
+    its il_policy, rl/train.py:130-133): with the persistent simulator enabled once and env.reset() per episode the
+    robot's actions, rewards and terminal classes are the reference's in EVERY episode; without it they are not."""
+    z, params, N, S, batches = il_persistent_episodes(name, copies)
+    safety = float(z["safety_space"])
+    tile = lambda b: b  # noqa: E731
+    env = make_env(params, copies, N, S)
+    env.robot_orca_sim(True)
+    for k, b in enumerate(batches):
+        env.reset(tile(b))
+        for t in range(len(z["action%d" % k])):
+            a = env.robot_orca(safety)
+            np.testing.assert_allclose(a[0], z["action%d" % k][t], atol=1e-9, rtol=0, err_msg="episode %d step %d" % (k, t))
+            assert (a == a[0:1]).all()
+            out = env.step(robot_action=a, human_policy=_abi.HUMAN_ORCA)
+            np.testing.assert_allclose(out["reward"][0], z["reward%d" % k][t], atol=1e-9, rtol=0)
+            assert int(out["info"][0]) == int(z["info%d" % k][t]), (k, t)
+        assert bool(out["done"][0])
+    # the fixture has teeth: a fresh simulator per call departs from the reference once the radii have changed
+    if not bool(z["sim_rebuilt"][1:].all()):
+        env.robot_orca_sim(False)
+        differs = False
+        for k, b in enumerate(batches[:2]):
+            env.reset(tile(b))
+            for t in range(len(z["action%d" % k])):
+                a = env.robot_orca(safety)
+                differs = differs or not np.allclose(a[0], z["action%d" % k][t], atol=1e-9, rtol=0)
+                env.step(robot_action=np.tile(z["action%d" % k][t], (copies, 1)), human_policy=_abi.HUMAN_ORCA)
+        assert differs

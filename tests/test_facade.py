@@ -280,3 +280,51 @@ def test_policy_transform_without_env_is_the_reference_rotate():
                         [ObservableState(*[float(x) for x in q[9:14]], int(q[14])) for q in rows[:5]])
         want = pol.rotate(torch.Tensor([list(r[:9]) + list(q[9:15]) for q in rows[:5]]))
         np.testing.assert_array_equal(pol.transform(js).numpy(), want.numpy())
+
+
+def _facade_il_episodes(name, backend):
+    """rl/train.py:120-133 + explorer.py:33-45 through the facade: ONE ORCA policy object given to the robot plays the
+    fixture's consecutive `train` episodes (env.reset("train") draws the reference's seeds); its actions are the
+    reference's in every episode — the object keeps its simulator (radii of the episode that built it)."""
+    import configparser
+    from ebcsim import env as ebc_env
+    from ebcsim.agents import Robot
+    from ebcsim.policy import policy_factory
+    from helpers import config_text_of
+    z = load(name)
+    meta = json.loads(str(z["meta"]))
+    cfg = configparser.RawConfigParser()
+    cfg.read_string(config_text_of(meta))
+    env = ebc_env.make(backend_factory=backend)
+    env.configure(cfg)
+    robot = Robot(cfg, "robot")
+    il_policy = policy_factory["orca"]()
+    il_policy.multiagent_training = True
+    il_policy.safety_space = float(z["safety_space"])
+    robot.set_policy(il_policy)
+    env.set_robot(robot)
+    il_policy.set_phase("train")
+    for k in range(int(z["n_episodes"])):
+        ob, _, local_map = env.reset("train")
+        assert len(ob) == int(z["rows"][k])
+        done, t = False, 0
+        while not done:
+            action = robot.act(ob, local_map=local_map, env=env)
+            np.testing.assert_allclose([action.vx, action.vy], z["action%d" % k][t], atol=1e-9, rtol=0,
+                                       err_msg="episode %d step %d" % (k, t))
+            ob, local_map, reward, done, info = env.step(action)
+            assert abs(reward - z["reward%d" % k][t]) <= 1e-9
+            t += 1
+        assert t == len(z["action%d" % k])
+
+
+@pytest.mark.parametrize("name", ["il_persistent_const_rows", "il_persistent_wall_rows"])
+def test_orca_policy_object_keeps_its_simulator_cpu_backend(name):
+    from oracle import oracle
+    _facade_il_episodes(name, lambda p, E, N, S: oracle.OracleEnv(p, E, N, S))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["il_persistent_const_rows", "il_persistent_wall_rows"])
+def test_orca_policy_object_keeps_its_simulator_gpu(name):
+    _facade_il_episodes(name, None)

@@ -247,6 +247,13 @@ def test_scene_pool_semantics_cpu():
             np.testing.assert_array_equal(env2.get_state()["px"], b.px)
 
 
+@pytest.mark.parametrize("name", ["il_persistent_const_rows", "il_persistent_wall_rows"])
+def test_demonstrator_keeps_its_simulator_across_episodes(name):
+    """simulator/policy/orca.py:96-133 + rl/train.py:130-133: the reference's own IL loop on one il_policy."""
+    from helpers import check_il_persistent
+    check_il_persistent(lambda p, E, N, S: oracle.OracleEnv(p, E, N, S), name)
+
+
 def test_scene_pool_reinstalled_on_running_episodes_cpu():
     """A running env keeps the map of the scene it is on when the pool is replaced (smaller, then larger)."""
     from helpers import pool_reinstall_run

@@ -544,3 +544,55 @@ def test_il_targets_kernel_equals_the_host_scan():
     v_dev, k_dev = il_value_targets(r.cuda(), done.cuda(), 0.93, info.cuda())  # CUDA tensors: the kernel
     assert torch.equal(k_dev.cpu(), k_host)
     torch.testing.assert_close(v_dev.cpu(), v_host, atol=1e-12, rtol=0)
+
+
+def _collect_il_reproduces_reference_memory(make_env, device, name):
+    """The reference's whole IL stage on one il_policy (Explorer.run_k_episodes(k, "train", update_memory=True,
+    imitation_learning=True), rl/train.py:130-133) against ONE collect_il call: env 0 = that policy object, episode 0 by
+    reset, the following episodes as its scene pool (restarts inside ebc_step_k), the persistent simulator of
+    simulator/policy/orca.py:96-133 inside the kernel.  The replay memory ends up with the reference's states and
+    discounted returns, in its order (timeouts left out, explorer.py:82-92)."""
+    from ebcsim.scene import SceneBatch
+    from ebcsim.train import DeviceReplay, collect_il
+    from helpers import il_persistent_episodes
+    z, params, N, S, batches = il_persistent_episodes(name)
+    K = len(batches)
+    env = make_env(params, 1, N, S)
+    env.reset(batches[0])
+    pool = SceneBatch(K - 1, N, S, *[None if getattr(batches[0], f) is None and f == "grid" else
+                                     np.concatenate([(getattr(b, f) if getattr(b, f) is not None else
+                                                      np.zeros((1, env_G(params), 2), np.uint64)) for b in batches[1:]], 0)
+                                     for f in ("n_humans", "px", "py", "vx", "vy", "gx", "gy", "radius", "v_pref", "type",
+                                               "n_static", "spx", "spy", "sradius", "grid", "robot")])
+    env.set_scene_pool(pool, stride=1)
+    env.use_torch_stream()
+    steps = sum(len(z["action%d" % k]) for k in range(K))
+    R, T = N + S, z["il_state"].shape[1]
+    mem = DeviceReplay(steps + 8, R, T, device)
+    stored, episodes = collect_il(env, mem, steps, float(z["il_gamma"]), float(z["safety_space"]))
+    assert episodes == K and stored == len(z["il_value"]) == len(z["il_state_rows"])
+    np.testing.assert_allclose(mem.values[:stored].cpu().numpy(), z["il_value"], atol=1e-6, rtol=0)
+    rows = z["il_state_rows"]
+    np.testing.assert_array_equal(mem.n_valid[:stored].cpu().numpy(), rows)
+    off = np.concatenate([[0], np.cumsum(rows)])
+    st = mem.states[:stored].cpu().numpy()
+    for q in range(stored):
+        np.testing.assert_allclose(st[q, :rows[q]], z["il_state"][off[q]:off[q + 1]], atol=1e-5, rtol=1e-5, err_msg=str(q))
+        assert not st[q, rows[q]:].any()
+
+
+def env_G(params):
+    return int(round(params.map_size_m / params.map_resolution))
+
+
+@pytest.mark.parametrize("name", ["il_persistent_const_rows", "il_persistent_wall_rows"])
+def test_collect_il_reproduces_the_reference_il_stage_cpu(name):
+    from helpers import CpuDeviceEnv
+    _collect_il_reproduces_reference_memory(CpuDeviceEnv, "cpu", name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["il_persistent_const_rows", "il_persistent_wall_rows"])
+def test_collect_il_reproduces_the_reference_il_stage_gpu(name):
+    from ebcsim.batched import BatchedEnv
+    _collect_il_reproduces_reference_memory(lambda p, E, N, S: BatchedEnv(p, E, N, S), "cuda:0", name)
