@@ -7,6 +7,11 @@ the reference root — never copied) against THIS repo's `simulator` package, in
     dropin_driver.py <reference_root> episode <golden>   rl's SARL policy + Explorer-style loop on this
                                                          repo's env (oracle backend), against the golden
                                                          the reference's own simulator produced
+    dropin_driver.py <reference_root> train <output_dir> rl/train.py's run_train, unchanged, with the parameters of
+                                                         the reference's own smoke test (tests/test_basic_train.py:
+                                                         46-92): 3 IL episodes on its ORCA demonstrator, then RL
+                                                         rounds whose episodes run in its Pool(8) workers, each of
+                                                         which rebuilds the env from the config files
 
 `gym` and `cv2` are absent from the image: a registry-only `gym` stand-in (what rl/test.py:93 and
 simulator/__init__.py use of it) is installed; it is test scaffolding, not product code."""
@@ -19,7 +24,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def install_gym():
+def install_gym(backend_factory=None):
+    """backend_factory: TEST-side injection of the checker as the env's backend (there is no GPU in the build
+    container): every env `gym.make` builds gets it — also in the Pool workers of rl/utils/parallel_explorer.py,
+    which fork from this process and inherit this module.  Product code has no such switch."""
     gym = types.ModuleType("gym")
     registry = {}
 
@@ -28,7 +36,8 @@ def install_gym():
 
     def make(id):
         mod, cls = registry[id].split(":")
-        return getattr(__import__(mod, fromlist=[cls]), cls)()
+        klass = getattr(__import__(mod, fromlist=[cls]), cls)
+        return klass(backend_factory=backend_factory) if backend_factory is not None else klass()
 
     class Env(object):
         pass
@@ -42,13 +51,59 @@ def install_gym():
     sys.modules.update({"gym": gym, "gym.envs": envs, "gym.envs.registration": reg})
 
 
+import collections  # noqa: E402
+
+# module level: the reference pickles it into its Pool workers (tests/test_basic_train.py:15-29)
+Params = collections.namedtuple("Params", ["env_config", "policy", "policy_config", "train_config", "output_dir",
+                                           "resume", "gpu", "debug", "end_iteration"])
+
+
+def run_train_smoke(ref, output_dir):
+    """tests/test_basic_train.py:46-92 of the reference: its Params, its policy set-up, its
+    configure_environment_and_robot and its run_train — called, not restated."""
+    import configparser
+    import logging
+    import torch
+    from rl.policy.policy_factory import policy_factory
+    from rl.train import configure_environment_and_robot, run_train
+    import rl.train as rl_train
+    assert os.path.realpath(rl_train.__file__).startswith(os.path.realpath(ref))
+    cfg = lambda *p: os.path.join(ref, "configs", "test_configs", *p)  # noqa: E731
+    params = Params(env_config=cfg("test_env_configs", "env_adults_3_bikes_3_child_3_static_3_fast_train.config"),
+                    policy="sarl", policy_config=cfg("test_policy_configs", "policy.config"),
+                    train_config=cfg("test_train_configs", "test_train.config"), output_dir=output_dir, resume=False,
+                    gpu=False, debug=False, end_iteration=0)
+    logging.basicConfig(level=logging.INFO, handlers=[logging.FileHandler(os.path.join(output_dir, "output.log"), mode="w")],
+                        format="%(asctime)s, %(levelname)s: %(message)s")
+    policy = policy_factory[params.policy]()
+    policy_config = configparser.RawConfigParser()
+    policy_config.read(params.policy_config)
+    policy.configure(policy_config)
+    policy.set_device(torch.device("cpu"))
+    robot, env = configure_environment_and_robot(params, "EntityBasedCollisionAvoidance-v0")
+    import ebcsim.env
+    assert type(env) is ebcsim.env.EntityBasedCollisionAvoidance
+    explorer, episode = run_train(params, policy, env, robot)
+    log = open(os.path.join(output_dir, "output.log")).read()
+    print(json.dumps({"episode": episode, "files": sorted(os.listdir(output_dir)),
+                      "il_memory_logged": "Experience set size" in log,
+                      "runtime_errors_logged": log.count("Caught RuntimeError"),
+                      "train_episode_lines": log.count("TRAIN"), "val_episode_lines": log.count("VAL")}))
+
+
 def main():
     ref, mode = sys.argv[1], sys.argv[2]
-    install_gym()
     # this repo's `simulator` first, the reference root (for `rl`) after it
     sys.path[:0] = [os.path.join(ROOT, "eb-cadrl_amd"), ROOT, HERE, ref]
+    if mode == "train":
+        from oracle import oracle
+        install_gym(lambda params, E, N, S: oracle.OracleEnv(params, E, N, S))
+    else:
+        install_gym()
     import simulator
     assert os.path.realpath(simulator.__file__).startswith(os.path.realpath(ROOT)), simulator.__file__
+    if mode == "train":
+        return run_train_smoke(ref, sys.argv[3])
     if mode == "imports":
         import importlib
         names = ["rl.test", "rl.train", "rl.test_parallel", "rl.utils.explorer", "rl.utils.parallel_explorer",

@@ -279,3 +279,21 @@ def test_reference_known_answer_runs_on_this_env(name):
     run_scene_simulation on the frozen scene, with the reference's own SARL policy object on this env."""
     out = _driver("episode", name)
     assert out["max_value_err"] <= 5e-5 and out["orca_evaluations"] == out["steps"]
+
+
+@needs_reference
+def test_reference_run_train_runs_unchanged_on_this_env(tmp_path):
+    """rl/train.py:152-276 (`run_train`), called with the parameters of the reference's own smoke test
+    (tests/test_basic_train.py:46-92; env_adults_3_bikes_3_child_3_static_3_fast_train.config): 3 imitation-learning
+    episodes on the ORCA demonstrator (this package's `simulator.policy.orca.ORCA` through Explorer), a validation sweep
+    and a round of 8 train episodes in the reference's Pool(8) workers — each of which rebuilds THIS env from the
+    config files and drives it with the pickled SARL policy (81 onestep_lookahead calls per decision) —, optimize_batch,
+    checkpoints.  Pass = the reference's criterion (no exception) + its weight files written and loadable here."""
+    from ebcsim.sarl import SarlValueNet
+    out = _driver("train", str(tmp_path))
+    assert out["episode"] == 8 and out["runtime_errors_logged"] == 0 and out["il_memory_logged"]
+    assert {"il_model.pth", "rl_model_8.pth"} <= set(out["files"])
+    assert out["train_episode_lines"] >= 8 and out["val_episode_lines"] >= 2
+    for f in ("il_model.pth", "rl_model_8.pth"):
+        net = SarlValueNet.load(os.path.join(str(tmp_path), f))
+        assert net is not None
