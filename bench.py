@@ -540,6 +540,15 @@ def main():
     from ebcsim import shard
     elapsed_max, total_humans = shard.job_rate(elapsed, float(batch.n_humans.sum()),
                                               device=dev if backend == "nccl" else None)
+    gpu_open = None
+    if rehearsal:  # how many rank processes hold the GPU's device files (the one-GPU box's process guard counts them)
+        held = 0
+        for f in os.listdir("/proc/self/fd"):
+            try:
+                held |= "kfd" in os.readlink("/proc/self/fd/" + f)
+            except OSError:
+                pass
+        _, gpu_open = shard.job_rate(0.0, float(held), device=None)
     try:
         if on_gpu:
             env.synchronize()  # also reports a mailbox fault of any step above (EBC_ERR_DEVICE)
@@ -587,6 +596,7 @@ def main():
             # --rehearsal-gpu-ranks, stay on the host): the N-rank code path ran, `value` is NOT a scaling number
             "timing": "rehearsal" if rehearsal else "measured",
             "ranks_on_gpu": (min(world, args.rehearsal_gpu_ranks) if args.rehearsal_gpu_ranks > 0 else world) if rehearsal else world,
+            "ranks_with_gpu_open": None if gpu_open is None else int(gpu_open),
             "config": {"workload": "%s: %d envs/GPU x %d humans + %d static rows, ORCA + kinematics + "
                                    "collisions + reward + rotated obs (T=%d), one ebc_step (one HIP launch) per step, "
                                    "auto-reset%s" % (args.workload, E, batch.N, batch.S, env.T,
