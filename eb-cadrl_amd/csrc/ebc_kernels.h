@@ -78,6 +78,14 @@ struct DevState {
   unsigned *rows_loaded;          // [E] ROWS -> STATE: = epoch once the pre-step state AND the robot's next state are in registers
   unsigned *robot_ready;          // [E] ENV -> ROWS: = epoch once robot_n[e] holds this step's result
   unsigned *fault;                // [1] a poll gave up (protocol broken); ebc_synchronize reports it
+  // Second form of the fused ORCA step (orca_step2_kernel): an ORCA group commits its own human, so the humans'
+  // next positions / velocities and the next float tile go to SECOND buffers (the pre-step ones are still being
+  // read by other waves of the launch); the host swaps the pairs after the launch, like robot / robot_n.
+  double *px_n, *py_n, *vx_n, *vy_n;
+  float4 *tile_n;
+  uint4 *frame;         // [E][4] ENV1 -> row writers: the robot-centric frame of the NEXT robot state (rotate()), 3 floats + epoch each
+  uint4 *ract;          // [E][4] ENV1 -> ENV2: robot action a0, a1 and next position x, y as {lo, hi, epoch, epoch}
+  unsigned *committed;  // [E][N] ORCA -> ENV2 (restarts only): = epoch once the human's next state is in memory
   ScenePool pool;  // where auto-reset takes an env's next scene from
   // what rvo2 would hold for the current state (float), one 32-byte record per human slot:
   // tile[2k] = (position, velocity), tile[2k + 1] = (radius + 0.01 + safety, maxSpeed, preferred
@@ -194,9 +202,41 @@ __device__ __forceinline__ OrcaHot orca_hot(const DevState &s) {
   return OrcaHot{s.E, s.N, s.n_magic, s.n_shift, s.tile, s.n_humans};
 }
 
+// What an ORCA lane loads before anything else: its human's tile record and "other" j of it.
+struct OrcaTile {
+  float4 a, b, c;
+  float orad;
+  int n;
+};
 template <int GS>
-__device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s, const OrcaHot &hot, bool h_ok, int e, int i,
-                                          unsigned char *scratch, float &ox, float &oy, bool &human_ok) {
+__device__ __forceinline__ OrcaTile orca_tile_load(const OrcaHot &hot, bool h_ok, int e, int i) {
+  const int N = hot.N;
+  const int lane = threadIdx.x & (EBC_WAVE - 1);
+  const int group = lane / GS;
+  const int j = lane - group * GS;  // "other" index in ob order
+  OrcaTile t;
+  t.n = h_ok ? hot.n_humans[e] : 0;
+  const size_t base = (size_t)e * N;
+  // tile loads do not wait for n_humans: indices are clamped into the env's row, validity is
+  // decided afterwards (padded slots hold zeros)
+  const size_t ks = base + i;
+  const int oj = j < i ? j : j + 1;  // humans before / after this one
+  const size_t ko = base + (oj < N ? oj : N - 1);
+  t.a = t.b = t.c = make_float4(0, 0, 0, 0);
+  t.orad = 0;
+  if (h_ok) {
+    t.a = hot.tile[2 * ks];
+    t.b = hot.tile[2 * ks + 1];
+    t.c = hot.tile[2 * ko];
+    t.orad = hot.tile[2 * ko + 1].x;
+  }
+  return t;
+}
+
+template <int GS, typename Hook = NoHook>
+__device__ __forceinline__ void orca_wave_compute(const EbcParams &p, const DevState &s, const OrcaHot &hot, const OrcaTile &t,
+                                                  bool h_ok, int e, int i, unsigned char *scratch, float &ox, float &oy,
+                                                  bool &human_ok, Hook after_rank = Hook()) {
   using L = OrcaLds<GS>;
   float *dist_lds = reinterpret_cast<float *>(scratch);
   float4 *lines_lds = reinterpret_cast<float4 *>(scratch + L::DIST);
@@ -205,34 +245,12 @@ __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s,
   const int N = hot.N;
   const int lane = threadIdx.x & (EBC_WAVE - 1);
   const int group = lane / GS;
-  const int j = lane - group * GS;  // "other" index in ob order
-  const int n = h_ok ? hot.n_humans[e] : 0;
+  const int j = lane - group * GS;
+  const int n = t.n;
   human_ok = h_ok && i < n;
-  const size_t base = (size_t)e * N;
-  // tile loads do not wait for n_humans: indices are clamped into the env's row, validity is
-  // decided afterwards (padded slots hold zeros)
-  const size_t ks = base + i;
-  const int oj = j < i ? j : j + 1;  // humans before / after this one
-  const size_t ko = base + (oj < N ? oj : N - 1);
-  float posx = 0, posy = 0, velx = 0, vely = 0, radius = 0, maxSpeed = 0, prefx = 0, prefy = 0;
-  float opx = 0, opy = 0, ovx = 0, ovy = 0, orad = 0;
-  if (h_ok) {
-    const float4 a = hot.tile[2 * ks], b = hot.tile[2 * ks + 1];
-    const float4 c = hot.tile[2 * ko];
-    orad = hot.tile[2 * ko + 1].x;
-    posx = a.x;
-    posy = a.y;
-    velx = a.z;
-    vely = a.w;
-    radius = b.x;
-    maxSpeed = b.y;
-    prefx = b.z;
-    prefy = b.w;
-    opx = c.x;
-    opy = c.y;
-    ovx = c.z;
-    ovy = c.w;
-  }
+  const float posx = t.a.x, posy = t.a.y, velx = t.a.z, vely = t.a.w;
+  const float radius = t.b.x, maxSpeed = t.b.y, prefx = t.b.z, prefy = t.b.w;
+  float opx = t.c.x, opy = t.c.y, ovx = t.c.z, ovy = t.c.w, orad = t.orad;
   const int n_others = human_ok ? (n - 1 + (p.robot_visible ? 1 : 0)) : 0;
   const bool valid = j < n_others;
   if (p.robot_visible && valid && j == n - 1) {  // the robot, last in ob (env.py:401-402)
@@ -246,7 +264,14 @@ __device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s,
   orca_group<GS>(p, j, group, valid, posx, posy, velx, vely, radius, maxSpeed, prefx, prefy, opx, opy, ovx,
                  ovy, orad, dist_lds + group * L::Sh::DIST, lines_lds + group * L::Sh::LINES,
                  segs_lds + group * L::Sh::LINES, proj_lds + group * L::Sh::LINES,
-                 N - 1 + (p.robot_visible ? 1 : 0), s.range_sq, s.inv_time_horizon, s.inv_time_step, ox, oy);
+                 N - 1 + (p.robot_visible ? 1 : 0), s.range_sq, s.inv_time_horizon, s.inv_time_step, ox, oy, after_rank);
+}
+
+template <int GS>
+__device__ __forceinline__ void orca_wave(const EbcParams &p, const DevState &s, const OrcaHot &hot, bool h_ok, int e, int i,
+                                          unsigned char *scratch, float &ox, float &oy, bool &human_ok) {
+  const OrcaTile t = orca_tile_load<GS>(hot, h_ok, e, i);
+  orca_wave_compute<GS>(p, s, hot, t, h_ok, e, i, scratch, ox, oy, human_ok);
 }
 
 // (env, slot) of flat human index h < E * N without the ~20-instruction integer divide
@@ -575,7 +600,10 @@ __device__ __forceinline__ void store16_device(uint4 *box, u32x4 v) {
   __hip_atomic_store((unsigned long long *)box, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __hip_atomic_store((unsigned long long *)box + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-  asm volatile("global_store_dwordx4 %0, %1, off " EBC_VEL_STORE_SCOPE ::"v"(box), "v"(v) : "memory");
+  // s_nop: a store of more than 64 bits reads its data registers over several cycles, and a vector instruction that
+  // rewrites them right behind it corrupts the lanes read last (12-15 of every 16: seen).  The compiler pads that
+  // hazard for stores it emits itself; it cannot see inside an asm statement.
+  asm volatile("global_store_dwordx4 %0, %1, off " EBC_VEL_STORE_SCOPE "\n\ts_nop 2" ::"v"(box), "v"(v) : "memory");
 #endif
 }
 // wave-wide: returns once every lane with `need` has found its velocity word tagged with this launch's
@@ -656,6 +684,9 @@ struct EnvScratch {  // LDS of one service_env wave
   double ract[EBC_WAVE][2];  // the envs' robot actions
   double gtime[EBC_WAVE];    // per env: global time, parked from its early load to the reward at the end
   int n[EBC_WAVE];           // per env: its number of humans, parked for the leader's walk over them
+  // second form of the step (env2_role): more of what only an env's leader lane needs at the end
+  double goal[EBC_WAVE][2];
+  int slot[EBC_WAVE], cursor[EBC_WAVE];
 };
 // humans(): the lane's human (position, velocity, radius, type) — asked for AFTER the robot's action has been
 // worked out and published.  The fused step's ENV role loads its humans only then: double-precision
@@ -1362,6 +1393,9 @@ __device__ __forceinline__ void state_role(const EbcParams &p_in, const DevState
 #ifndef EBC_STEP_WPB
 #define EBC_STEP_WPB 1
 #endif
+__device__ __forceinline__ void env_lane_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in, RoleLds &L,
+                                              unsigned block, unsigned epoch, int lane);
+
 template <int GS, int T>
 __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void orca_step_kernel(
     // 14 dwords the wave finds in scalar registers when it starts (kernarg preload): its role and, for
@@ -1401,7 +1435,11 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
 #else
   if (b < env_blocks) {
     __builtin_amdgcn_s_setprio(EBC_ENV_PRIO);  // the long dependent chain of the launch
-    if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, g.epoch, lane);
+    if (hot_pad) {  // lane = env (round 3)
+      if (EBC_ROLE_MASK & 1) env_lane_role(p_in, s_in, io_in, L, b, g.epoch, lane);
+    } else {
+      if (EBC_ROLE_MASK & 1) env_role(p_in, s_in, io_in, L, (int)b, g.epoch, lane);
+    }
     return;
   }
   b -= env_blocks;
@@ -1421,6 +1459,622 @@ __global__ __launch_bounds__(EBC_WAVE * EBC_STEP_WPB, EBC_STEP_WAVES(GS)) void o
   }
   b -= g.rows_blocks;
   if (EBC_ROLE_MASK & 8) state_role(p_in, s_in, io_in, L, (int)b, g.rows_blocks != 0, g.epoch, lane);
+}
+
+// ---- ENV with EBC_ENV_LANES lanes per ENV (round 3).  The ENV role above maps a lane to a human slot: 6 envs per wave
+// at N = 10, so the robot's policy (double-precision atan2 / sin / cos), the grid window and the reward run on 6 lanes
+// of 64 — 683 waves that, with the 5 852 ORCA waves, exceed the 6 144 resident slots: 391 ORCA waves start 5 us late
+// and the launch ends with them (profiles/r02_wave_timeline_marks.txt).  Here an env has 4 lanes (16 envs per wave,
+// 256 waves at 4096 envs: ENV + ORCA waves all fit at once): each walks a contiguous quarter of the env's humans —
+// the serial form of env.py:303-313 with its break per type — and the quarters are combined in order.  (A lane per
+// env, 64 waves, was tried first: its 10-human serial walk made the role 14.8 us long and everything waited for
+// env_done, profiles/r03_env_lane_timeline.txt.)  Same mailboxes as ENV: robot_n + robot_ready early, env_done last.
+#define EBC_ENV_LANES 4
+__device__ __forceinline__ void env_lane_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in, RoleLds &L,
+                                              unsigned block, unsigned epoch, int lane) {
+  stage_args(&L.args.p, p_in, lane);
+  stage_args(&L.args.s, s_in, lane);
+  stage_args(&L.args.io, io_in, lane);
+  wave_sync();
+  const EbcParams &p = L.args.p;
+  const DevState &s = L.args.s;
+  const StepIO &io = L.args.io;
+  constexpr int Q = EBC_ENV_LANES, EPW = EBC_WAVE / Q;
+  const int el = lane / Q, part = lane - el * Q;
+  const int e0 = (int)block * EPW;
+  const int e = e0 + el;
+  const bool ok = e < s.E;
+  const size_t ee = ok ? (size_t)e : 0;
+  const int N = s.N;
+  double rb[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) rb[c] = ok ? s.robot[ee * 9 + c] : 0.0;
+  const int n = ok ? s.n_humans[ee] : 0;
+  double gtime = ok ? s.time[ee] : 0.0;
+  int grid_slot = (ok && s.pool.grid) ? s.grid_scene[ee] : 0;
+  const int chunk = (N + Q - 1) / Q;
+  const int i0 = part * chunk;
+  pin(gtime); pin(grid_slot);
+#pragma unroll
+  for (int c = 0; c < 9; ++c) pin(rb[c]);
+  double a0 = 0, a1 = 0;
+  if (ok) robot_action(io, ee, rb, a0, a1);
+  EBC_MARK(1);
+  {  // the robot's next state, published early: the ROWS role builds the observation frame from it
+    double rn[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) rn[c] = rb[c];
+    robot_advance(p, rn, a0, a1);
+    double *stage = &L.env.cand[0][0];  // 3 x 64 doubles >= 16 robots
+    if (part == 0) {
+#pragma unroll
+      for (int c = 0; c < 9; ++c) stage[el * 9 + c] = rn[c];
+      // what only the env's first lane needs at the end: parked, out of the registers of the distance work
+      L.env.gtime[el] = gtime;
+      L.env.slot[el] = grid_slot;
+      L.env.goal[el][0] = rb[5];
+      L.env.goal[el][1] = rb[6];
+      L.env.ract[el][0] = rn[0];  // the next position (Agent.compute_position): robot_advance's
+      L.env.ract[el][1] = rn[1];
+    }
+    wave_sync();
+    const int here = min(EPW, s.E - e0);
+    for (int q = lane; q < 9 * here; q += EBC_WAVE)
+      __hip_atomic_store(s.robot_n + (size_t)e0 * 9 + q, stage[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // this lane's quarter of the humans, asked for only now: they do not fit the 80-register budget beside the
+  // double-precision atan2 / sin / cos of the robot's policy (60 spilled registers when loaded up front)
+  constexpr int PRE = 2;  // humans per lane that are loaded together (N <= 8: all of them; a third comes as it is reached)
+  double hpx[PRE], hpy[PRE], hvx[PRE], hvy[PRE], hr[PRE];
+  int ht[PRE];
+  {
+    const DevState &sl = read_late(s);
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+      const int i = i0 + q;
+      const bool have = ok && q < chunk && i < N;
+      const size_t k = ee * N + (have ? i : 0);
+      hpx[q] = have ? sl.px[k] : 0.0; hpy[q] = have ? sl.py[k] : 0.0; hvx[q] = have ? sl.vx[k] : 0.0; hvy[q] = have ? sl.vy[k] : 0.0;
+      hr[q] = have ? sl.radius[k] : 0.0;
+      ht[q] = have ? (int)sl.type[k] : 0;
+    }
+  }
+  double rvx, rvy;
+  if (p.robot_kinematics == EBC_HOLONOMIC) {
+    rvx = a0;
+    rvy = a1;
+  } else {
+    rvx = a0 * cos(a1 + rb[8]);
+    rvy = a0 * sin(a1 + rb[8]);
+  }
+  // compute_collisions (env.py:303-338) over this lane's humans: per type in index order, break at the first hit
+  double dmin[3] = {INFINITY, INFINITY, INFINITY};
+  int coll[4] = {0, 0, 0, 0};
+  auto visit = [&](double px, double py, double vx, double vy, double r, int t) {
+    const double d = closest_dist(px, py, vx, vy, r, rb[0], rb[1], rb[4], rvx, rvy, p.time_step);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (t == q && !coll[q]) {
+        if (d < 0) coll[q] = 1;
+        else if (d < dmin[q]) dmin[q] = d;
+      }
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < PRE; ++q)
+    if (q < chunk && i0 + q < n) visit(hpx[q], hpy[q], hvx[q], hvy[q], hr[q], ht[q]);
+  for (int q = PRE; q < chunk; ++q) {  // N > 12: the rest of the quarter, loaded as it is reached
+    const int i = i0 + q;
+    if (!__any(i < n)) break;
+    if (i < n) {
+      const size_t k = ee * N + i;
+      visit(s.px[k], s.py[k], s.vx[k], s.vy[k], s.radius[k], (int)s.type[k]);
+    }
+  }
+  // the robot's stores went out a distance computation ago: this wait is short
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (ok && part == 0) mailbox_put(s.robot_ready + ee, epoch);
+  // the quarters in order: a later quarter counts for a type only while no earlier one has hit it
+  double fm[3] = {INFINITY, INFINITY, INFINITY};
+  int fc[3] = {0, 0, 0};
+  const int base = lane - part;
+#pragma unroll
+  for (int src = 0; src < Q; ++src) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const double od = __shfl(dmin[t], base + src, EBC_WAVE);
+      const int oc = __shfl(coll[t], base + src, EBC_WAVE);
+      if (!fc[t]) {
+        fm[t] = od < fm[t] ? od : fm[t];
+        fc[t] = oc;
+      }
+    }
+  }
+  EBC_MARK(2);
+  if (ok && part == 0) {
+    const EnvScratch &XL = read_late(L.env);
+    const double nx = XL.ract[el][0], ny = XL.ract[el][1];
+    // (the grid window worked out earlier, beside the humans' loads, measured 0.5 us SLOWER per step: r03_step_forms_ab.txt)
+    int c4[4] = {fc[0], fc[1], fc[2], 0};
+    c4[3] = grid_collision(s.pool.grid ? s.pool.grid + (size_t)XL.slot[el] * s.G * 2 : nullptr, s.G, p.map_size_m,
+                           p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
+    EBC_MARK(3);
+    const RewardOut ro = reward_compute(p, nx, ny, XL.goal[el][0], XL.goal[el][1], rb[4], a1, XL.gtime[el], fm, c4);
+    s.done[ee] = (uint8_t)ro.done;
+    if (io.reward) io.reward[ee] = ro.reward;
+    if (io.done) io.done[ee] = (uint8_t)ro.done;
+    if (io.info) io.info[ee] = (uint8_t)ro.info;
+    if (io.dmin) {
+      io.dmin[3 * ee] = fm[0];
+      io.dmin[3 * ee + 1] = fm[1];
+      io.dmin[3 * ee + 2] = fm[2];
+    }
+    if (io.dist_to_goal) io.dist_to_goal[ee] = ro.dist_to_goal;
+    if (io.robot_action_out) {
+      io.robot_action_out[2 * ee] = a0;
+      io.robot_action_out[2 * ee + 1] = a1;
+    }
+    mailbox_put(s.env_done + ee, ((unsigned long long)epoch << 32) | (1u + (unsigned)ro.done));
+  }
+  EBC_MARK(4);
+}
+
+// =========================================================================== ORCA step, second form (round 3)
+// What the wave timeline of the four-role launch showed (profiles/r02_wave_timeline_marks.txt): the launch ends with
+// its CONSUMER roles.  A STATE wave starts at 8 us (last in dispatch order, when slots free up), needs 5.5 us for three
+// dependent memory round trips under the load of 2 000 polling waves, and stores 2.5 us after its mailboxes are full;
+// the last ORCA wave ends 2.8 us before the launch does; ENV + ORCA waves (6 535) exceed the 6 144 resident slots, so
+// 391 ORCA waves start 5 us late.  Here the hand-offs that sat on the tail are gone:
+//
+//   ENV1  lane = ENV (64 envs per wave, 64 waves at 4096 envs): the robot's action and next state (the double-precision
+//         atan2 / sin / cos of the linear policy at full lane occupancy instead of 6 lanes of 64), robot_n, and two
+//         epoch-tagged records per env: `ract` (action + next position, for ENV2) and `frame` (the robot-centric frame
+//         of rotate(), for every row writer).  Dispatched first; waits for nothing.
+//   ORCA  the lane group of a human, as before — and then lane 0 of the group COMMITS its human: next position, first
+//         arrival, the next float tile record (into the second buffers: other groups still read the current ones),
+//         the human's velocity and its raw / rotated observation row.  No velocity mailbox, no consumer wave, no hop
+//         between the LP and the state: the launch ends when its last ORCA wave does.  ENV1 + ORCA = 5 916 waves: all
+//         resident at once, none starts late.
+//   ENV2  lane = human slot (6 envs per wave): swept distances, ordered per-type reduce, grid window, reward / done /
+//         info, the rows of static obstacles and padding, time — nothing here waits for ORCA.  A terminal env under
+//         auto-reset (rare) waits for its humans' `committed` flags and writes the restart scene over their commits.
+//         Dispatched last: its waves start as ORCA waves finish, and are done before the slow ORCA waves are.
+//
+// Ordering of conflicting stores across XCDs (their L2s are not coherent): a commit that a restart may overwrite
+// leaves with write-through (sc1) stores and is drained (s_waitcnt vmcnt(0)) before the `committed` flag; the
+// restart's plain stores are written back at the end of the launch, after it.
+struct Step2Grid {
+  unsigned env1_blocks, orca_blocks, env2_blocks;
+  unsigned epoch;
+  unsigned total;
+};
+
+template <int GS>
+struct Step2Lds {
+  ArgBlock args;
+  union {
+    EnvScratch env;              // ENV2
+    double robots[EBC_WAVE][9];  // ENV1: the robots' next states, staged for one coalesced run of stores
+    struct {                     // ORCA: the LP's scratch, and what lane 0 of each group needs after the LP
+      unsigned char lp[(OrcaLds<GS>::BYTES + 15) / 16 * 16];
+      double v[(EBC_WAVE + GS - 1) / GS][7];  // px, py, gx, gy, radius, arrival, global time
+      int type[(EBC_WAVE + GS - 1) / GS];
+    } orca;
+  };
+};
+
+__device__ __forceinline__ void store16_sc1(void *dst, u32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(dst), "v"(v) : "memory");  // s_nop: see store16_device
+}
+__device__ __forceinline__ void store8_sc1(double *dst, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4 tag3(float a, float b, float c, unsigned epoch) {
+  return u32x4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), epoch};
+}
+__device__ __forceinline__ u32x4 tag_double(double v, unsigned epoch) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return u32x4{(unsigned)u, (unsigned)(u >> 32), epoch, epoch};
+}
+__device__ __forceinline__ double untag_double(u32x4 v) {
+  return __longlong_as_double((long long)(((unsigned long long)v.y << 32) | v.x));
+}
+
+// The frame record of env `ee` (4 granules written by ENV1): polled until every granule carries this launch's epoch.
+__device__ __forceinline__ RotFrame frame_wait(const uint4 *frame, size_t ee, bool need, unsigned epoch, unsigned *fault) {
+  u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = g0, g2 = g0, g3 = g0;
+  bool waiting = need;
+  for (unsigned spins = 0;; ++spins) {
+    if (waiting) {
+      const uint4 *b = frame + ee * 4;
+      asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                   "s_waitcnt vmcnt(0)"
+                   : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3) : "v"(b) : "memory");
+      waiting = g0.w != epoch || g1.w != epoch || g2.w != epoch || g3.w != epoch;
+    }
+    if (!__any(waiting)) break;
+    if (spins > EBC_SPIN_LIMIT) {
+      if (waiting) atomicOr(fault, 1u);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(EBC_POLL_SLEEP);
+  }
+  RotFrame f;
+  f.px = __uint_as_float(g0.x); f.py = __uint_as_float(g0.y); f.r = __uint_as_float(g0.z);
+  f.vpref = __uint_as_float(g1.x); f.c = __uint_as_float(g1.y); f.s = __uint_as_float(g1.z);
+  f.dg = __uint_as_float(g2.x); f.vx = __uint_as_float(g2.y); f.vy = __uint_as_float(g2.z);
+  f.theta = __uint_as_float(g3.x);
+  return f;
+}
+
+template <int T>
+__device__ __forceinline__ void emit_row(const StepIO &io, size_t row_index, const RotFrame &f, bool valid, double opx, double opy,
+                                         double ovx, double ovy, double orad, int otype) {
+  if (io.ob) {
+    double *o = io.ob + row_index * 5;
+    o[0] = valid ? opx : 0.0; o[1] = valid ? opy : 0.0; o[2] = valid ? ovx : 0.0; o[3] = valid ? ovy : 0.0; o[4] = valid ? orad : 0.0;
+  }
+  if (io.obs_rotated) {
+    float out[T];
+    if (valid) {
+      rotate_row<T>(f, opx, opy, ovx, ovy, orad, otype, out);
+    } else {
+#pragma unroll
+      for (int c = 0; c < T; ++c) out[c] = 0.0f;
+    }
+    float *o = io.obs_rotated + row_index * T;  // nobody on the device reads the rows: streaming stores
+#pragma unroll
+    for (int c = 0; c < T; ++c) __builtin_nontemporal_store(out[c], o + c);
+  }
+}
+
+// ---- ENV1: lane = env
+template <typename Lds>
+__device__ __forceinline__ void env1_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in, Lds &L,
+                                          unsigned block, unsigned epoch, int lane) {
+  stage_args(&L.args.p, p_in, lane);
+  stage_args(&L.args.s, s_in, lane);
+  stage_args(&L.args.io, io_in, lane);
+  wave_sync();
+  const EbcParams &p = L.args.p;
+  const DevState &s = L.args.s;
+  const StepIO &io = L.args.io;
+  const int e0 = (int)block * EBC_WAVE;
+  const int e = e0 + lane;
+  const bool ok = e < s.E;
+  const size_t ee = ok ? (size_t)e : 0;
+  double rb[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) rb[c] = ok ? s.robot[ee * 9 + c] : 0.0;
+  double a0 = 0, a1 = 0;
+  if (ok) robot_action(io, ee, rb, a0, a1);
+  robot_advance(p, rb, a0, a1);  // rb = the robot's next state (agent.py:202-228)
+  const RotFrame f = rot_frame(rb, p.rotate_unicycle);
+  bool publish = ok;
+#ifdef EBC_WAVE_TRACE  // test build only: the env of the withheld human never gets its records (tests the give-up path)
+  if (g_withhold_human >= 0 && e == g_withhold_human / s.N) publish = false;
+#endif
+  if (publish) {
+    uint4 *fr = s.frame + ee * 4, *ra = s.ract + ee * 4;
+    store16_sc1(fr, tag3(f.px, f.py, f.r, epoch));
+    store16_sc1(fr + 1, tag3(f.vpref, f.c, f.s, epoch));
+    store16_sc1(fr + 2, tag3(f.dg, f.vx, f.vy, epoch));
+    store16_sc1(fr + 3, tag3(f.theta, 0.0f, 0.0f, epoch));
+    store16_sc1(ra, tag_double(a0, epoch));
+    store16_sc1(ra + 1, tag_double(a1, epoch));
+    store16_sc1(ra + 2, tag_double(rb[0], epoch));
+    store16_sc1(ra + 3, tag_double(rb[1], epoch));
+    if (io.robot_action_out) {
+      io.robot_action_out[2 * ee] = a0;
+      io.robot_action_out[2 * ee + 1] = a1;
+    }
+  }
+  // robot_n: what the next step reads (a restart overwrites it later in this launch: write-through, so that the
+  // restart's write-back at the end of the launch comes after it).  One coalesced run for the wave's 64 envs.
+#pragma unroll
+  for (int c = 0; c < 9; ++c) L.robots[lane][c] = rb[c];
+  wave_sync();
+  const int envs_here = min(EBC_WAVE, s.E - e0);
+  for (int q = lane; q < 9 * envs_here; q += EBC_WAVE) store8_sc1(s.robot_n + (size_t)e0 * 9 + q, (&L.robots[0][0])[q]);
+}
+
+// ---- ORCA: the LP of v1, then lane 0 of each group commits its human and writes its observation row
+template <int GS, int T>
+__device__ __forceinline__ void orca_role2(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in, const OrcaHot &hot,
+                                           unsigned epoch, Step2Lds<GS> &L, unsigned block, int lane) {
+  constexpr int HPW = EBC_WAVE / GS;
+  const int group = lane / GS, j = lane - group * GS;
+  const unsigned hh = block * HPW + group;
+  const bool h_ok = group < HPW && hh < (unsigned)hot.E * (unsigned)hot.N;  // lanes past HPW * GS idle
+  int e, i;
+  split_human(hot, hh, h_ok, e, i);
+  // the tile loads go out first (their addresses come from preloaded arguments); the argument block follows them
+  // into LDS while they are in flight
+  const OrcaTile tile = orca_tile_load<GS>(hot, h_ok, e, i);
+  stage_args(&L.args.p, p_in, lane);
+  stage_args(&L.args.s, s_in, lane);
+  stage_args(&L.args.io, io_in, lane);
+  wave_sync();
+  const bool mine = h_ok && j == 0;
+  // what the commit needs of the human, asked for now (lane 0 of the group) and parked in LDS after the ranking:
+  // fifteen registers that must not live through the LP
+  double cpx = 0, cpy = 0, cgx = 0, cgy = 0, crad = 0, carr = 0, ctime = 0;
+  int ctype = 0;
+  if (mine) {
+    const DevState &s = L.args.s;
+    const size_t k = hh;
+    cpx = s.px[k]; cpy = s.py[k]; cgx = s.gx[k]; cgy = s.gy[k]; crad = s.radius[k]; carr = s.arrival[k];
+    ctype = s.type[k];
+    ctime = s.time[e];  // read NOW: ENV2 advances it while this launch runs
+  }
+  auto park = [&]() {
+    if (mine) {
+      double *v = L.orca.v[group];
+      v[0] = cpx; v[1] = cpy; v[2] = cgx; v[3] = cgy; v[4] = crad; v[5] = carr; v[6] = ctime;
+      L.orca.type[group] = ctype;
+    }
+  };
+  float ox, oy;
+  bool human_ok;
+  orca_wave_compute<GS>(L.args.p, L.args.s, hot, tile, h_ok, e, i, L.orca.lp, ox, oy, human_ok, park);
+  if (!mine) return;
+  const EbcParams &p = read_late(L.args.p);
+  const DevState &s = read_late(L.args.s);
+  const StepIO &io = read_late(L.args.io);
+  const size_t k = hh, ee = (size_t)e;
+  const int R = s.N + s.S;
+  const double *v = read_late(L.orca.v[group]);
+  double px = v[0], py = v[1];
+  const double gx = v[2], gy = v[3], rad = v[4], arrival = v[5], gtime = v[6];
+  const int type = read_late(L.orca.type[group]);
+  double ax = 0, ay = 0;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+  if (human_ok) {  // Agent.step (agent.py:202-211), first arrival (env.py:365-378), the next tile record (orca.py:110-140)
+    ax = (double)ox;  // getAgentVelocity -> Python float
+    ay = (double)oy;
+    px = px + ax * p.time_step;
+    py = py + ay * p.time_step;
+    const double dx = gx - px, dy = gy - py;
+    const double dist = norm2(dx, dy);
+    if (arrival == 0 && dist < rad) store8_sc1(s.arrival + k, gtime + p.time_step);
+    float prefx, prefy;
+    orca_pref_from(dx, dy, dist, prefx, prefy);
+    t0 = v4f{(float)px, (float)py, ox, oy};
+    t1 = v4f{tile.b.x, tile.b.y, prefx, prefy};  // radius + 0.01 + safety and maxSpeed do not change within an episode
+  } else {
+    px = py = 0.0;
+  }
+  // write-through: a restart of this env (ENV2, on another XCD) may overwrite these before the launch ends
+  store8_sc1(s.px_n + k, px);
+  store8_sc1(s.py_n + k, py);
+  store8_sc1(s.vx_n + k, ax);
+  store8_sc1(s.vy_n + k, ay);
+  {
+    u32x4 w0, w1;
+    __builtin_memcpy(&w0, &t0, 16);
+    __builtin_memcpy(&w1, &t1, 16);
+    store16_sc1(s.tile_n + 2 * k, w0);
+    store16_sc1(s.tile_n + 2 * k + 1, w1);
+  }
+  if (io.human_action) {
+    io.human_action[k * 2] = ax;
+    io.human_action[k * 2 + 1] = ay;
+  }
+  EBC_MARK(5);
+  if (io.ob || io.obs_rotated) {
+    // the human's row: row i, or — a padded slot — one of the zero rows behind the static ones (rows_role's map)
+    const RotFrame f = frame_wait(s.frame, ee, true, epoch, s.fault);
+    const int ns = (human_ok || !s.S) ? 0 : s.n_static[ee];
+    const int row = human_ok ? i : ns + i;
+    emit_row<T>(io, ee * R + row, f, human_ok, px, py, ax, ay, rad, type);
+  }
+  if (io.auto_reset) {  // the flag a restart waits for: behind the commit's stores, and behind this lane's last read of
+                        // anything a restart rewrites (n_static)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mailbox_put(s.committed + k, epoch);
+  }
+}
+
+// ---- ENV2: lane = human slot
+template <int T, typename Lds>
+__device__ __forceinline__ void env2_role(const EbcParams &p_in, const DevState &s_in, const StepIO &io_in, Lds &L,
+                                          unsigned block, unsigned epoch, int lane) {
+  stage_args(&L.args.p, p_in, lane);
+  stage_args(&L.args.s, s_in, lane);
+  stage_args(&L.args.io, io_in, lane);
+  wave_sync();
+  const EbcParams &p = L.args.p;
+  const DevState &s = L.args.s;
+  const StepIO &io = L.args.io;
+  EnvScratch &X = L.env;
+  const int N = s.N, S = s.S, R = N + S;
+  const int epb = EBC_WAVE / N;
+  const LaneMap m = lane_map(s, (int)block * epb, epb, lane);
+  // pre-step state: nothing of it is overwritten while this launch runs (commits go to the second buffers)
+  double rb[9];
+  load_robot(s, m, rb);
+  double gtime = m.env_ok ? s.time[m.ee] : 0.0;
+  HumanRegs h = load_human(s, m);
+  int grid_slot = (m.leader && s.pool.grid) ? s.grid_scene[m.ee] : 0;
+  int cursor = 0;
+  if (io.auto_reset && m.leader) cursor = s.pool.P > 0 ? s.pool.cursor[m.ee] : (int)m.ee;
+  pin(gtime); pin(grid_slot); pin(cursor);
+  pin(h.px); pin(h.py); pin(h.vx); pin(h.vy); pin(h.rad); pin(h.type);
+  if (m.leader) {  // what only the leader's tail needs: parked in LDS, out of the registers of the distance work
+    X.gtime[m.el] = gtime;
+    X.n[m.el] = m.n;
+    X.slot[m.el] = grid_slot;
+    X.cursor[m.el] = cursor;
+    X.goal[m.el][0] = rb[5];
+    X.goal[m.el][1] = rb[6];
+  }
+  // the robot's action and next position (ENV1)
+  double a0, a1, nx, ny;
+  {
+    u32x4 g0 = {0u, 0u, 0u, 0u}, g1 = g0, g2 = g0, g3 = g0;
+    bool waiting = m.env_ok;
+    for (unsigned spins = 0;; ++spins) {
+      if (waiting) {
+        const uint4 *b = s.ract + m.ee * 4;
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3) : "v"(b) : "memory");
+        waiting = g0.z != epoch || g0.w != epoch || g1.z != epoch || g1.w != epoch || g2.z != epoch || g2.w != epoch ||
+                  g3.z != epoch || g3.w != epoch;
+      }
+      if (!__any(waiting)) break;
+      if (spins > EBC_SPIN_LIMIT) {
+        if (waiting) atomicOr(s.fault, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(EBC_POLL_SLEEP);
+    }
+    a0 = untag_double(g0); a1 = untag_double(g1); nx = untag_double(g2); ny = untag_double(g3);
+  }
+  if (m.leader) {
+    X.ract[m.el][0] = nx;
+    X.ract[m.el][1] = ny;
+  }
+  EBC_MARK(1);
+  double rvx, rvy;
+  if (p.robot_kinematics == EBC_HOLONOMIC) {
+    rvx = a0;
+    rvy = a1;
+  } else {
+    rvx = a0 * cos(a1 + rb[8]);
+    rvy = a0 * sin(a1 + rb[8]);
+  }
+  // ordered per-type reduction with break at the first hit (env.py:303-313): service_env's form
+  const double d = m.active ? closest_dist(h.px, h.py, h.vx, h.vy, h.rad, rb[0], rb[1], rb[4], rvx, rvy, p.time_step) : 0.0;
+  const bool hit = m.active && d < 0;
+  const int base = lane - m.i;
+  int coll[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const unsigned long long hm = (__ballot(hit && h.type == t) >> base) & (N >= 64 ? ~0ull : ((1ull << N) - 1));
+    const int first = hm ? __ffsll((long long)hm) - 1 : N;
+    coll[t] = hm != 0;
+    X.cand[t][lane] = (m.active && h.type == t && !hit && m.i < first) ? d : INFINITY;
+  }
+  wave_sync();
+  EBC_MARK(2);
+  int done_flag = 0;
+  if (m.leader) {
+    const EnvScratch &XL = read_late(X);
+    const double nx = XL.ract[m.el][0], ny = XL.ract[m.el][1], gtime = XL.gtime[m.el];
+    const int n_env = XL.n[m.el];
+    double dm0 = INFINITY, dm1 = INFINITY, dm2 = INFINITY;
+    for (int q = 0; q < n_env; ++q) {
+      const double d0 = X.cand[0][lane + q], d1 = X.cand[1][lane + q], d2 = X.cand[2][lane + q];
+      dm0 = d0 < dm0 ? d0 : dm0;
+      dm1 = d1 < dm1 ? d1 : dm1;
+      dm2 = d2 < dm2 ? d2 : dm2;
+    }
+    const double dmin[3] = {dm0, dm1, dm2};
+    coll[3] = grid_collision(s.pool.grid ? s.pool.grid + (size_t)XL.slot[m.el] * s.G * 2 : nullptr, s.G, p.map_size_m,
+                             p.map_resolution, nx, ny, rb[4], io.has_border ? io.border : nullptr);
+    const RewardOut ro = reward_compute(p, nx, ny, XL.goal[m.el][0], XL.goal[m.el][1], rb[4], a1, gtime, dmin, coll);
+    done_flag = ro.done;
+    if (!(io.auto_reset && ro.done)) s.time[m.ee] = gtime + p.time_step;
+    s.done[m.ee] = (uint8_t)ro.done;
+    if (io.reward) io.reward[m.ee] = ro.reward;
+    if (io.done) io.done[m.ee] = (uint8_t)ro.done;
+    if (io.info) io.info[m.ee] = (uint8_t)ro.info;
+    if (io.dmin) {
+      io.dmin[3 * m.ee] = dm0;
+      io.dmin[3 * m.ee + 1] = dm1;
+      io.dmin[3 * m.ee + 2] = dm2;
+    }
+    if (io.dist_to_goal) io.dist_to_goal[m.ee] = ro.dist_to_goal;
+  }
+  EBC_MARK(3);
+  done_flag = __shfl(done_flag, base, EBC_WAVE);
+  const bool restore = m.env_ok && io.auto_reset && done_flag;
+  // the rows of static obstacles and the padding rows (rows_role's map: static j < ns -> n + j, else N + j)
+  if ((io.ob || io.obs_rotated) && S > 0) {
+    const RotFrame f = frame_wait(s.frame, m.ee, m.env_ok, epoch, s.fault);
+    for (int q = m.i; q < S; q += N) {
+      if (!m.env_ok) break;
+      const size_t c = m.ee * S + q;  // loaded here: ENV2 is not what the launch waits for
+      const double sx = s.spx[c], sy = s.spy[c], sr = s.sradius[c];
+      const bool valid = q < m.ns;
+      emit_row<T>(io, m.ee * R + (valid ? m.n + q : N + q), f, valid, sx, sy, 0.0, 0.0, sr, EBC_ADULT_STATIC);
+    }
+  }
+  EBC_MARK(4);
+  if (!__any(restore)) return;
+  // ---- a terminal env under auto-reset takes its next scene (rare): behind its humans' commits
+  mailbox_wait_epoch(s.committed + m.k, restore, epoch, s.fault);
+  if (!restore) return;
+  const ScenePool &P = s.pool;
+  cursor = read_late(X).cursor[m.el];
+  const size_t src = (size_t)cursor * N + m.i;
+  const int n_new = P.n_humans[cursor];
+  const bool live = m.i < n_new;
+  const double npx = live ? P.px[src] : 0.0, npy = live ? P.py[src] : 0.0, nvx = live ? P.vx[src] : 0.0, nvy = live ? P.vy[src] : 0.0;
+  const double nrad = live ? P.radius[src] : 0.0, nvp = live ? P.v_pref[src] : 0.0;
+  s.px_n[m.k] = npx; s.py_n[m.k] = npy; s.vx_n[m.k] = nvx; s.vy_n[m.k] = nvy;
+  s.arrival[m.k] = 0.0;
+  s.gx[m.k] = live ? P.gx[src] : 0.0;
+  s.gy[m.k] = live ? P.gy[src] : 0.0;
+  s.radius[m.k] = nrad;
+  s.v_pref[m.k] = nvp;
+  s.type[m.k] = live ? P.type[src] : (uint8_t)0;
+  if (live) {
+    const float2 rp = P.pref[src];
+    s.tile_n[2 * m.k] = make_float4((float)npx, (float)npy, (float)nvx, (float)nvy);
+    s.tile_n[2 * m.k + 1] = make_float4((float)(nrad + 0.01 + p.orca_safety_space), (float)nvp, rp.x, rp.y);
+  } else {
+    s.tile_n[2 * m.k] = make_float4(0, 0, 0, 0);
+    s.tile_n[2 * m.k + 1] = make_float4(0, 0, 0, 0);
+  }
+  for (int q = m.i; q < S; q += N) {
+    const size_t c = (size_t)cursor * S + q;
+    s.spx[m.ee * S + q] = P.spx[c];
+    s.spy[m.ee * S + q] = P.spy[c];
+    s.sradius[m.ee * S + q] = P.sradius[c];
+  }
+  if (m.leader) {
+    s.n_humans[m.ee] = n_new;
+    if (S) s.n_static[m.ee] = P.n_static[cursor];
+    s.grid_scene[m.ee] = cursor;
+    for (int q = 0; q < 9; ++q) s.robot_n[m.ee * 9 + q] = P.robot[(size_t)cursor * 9 + q];
+    s.time[m.ee] = 0.0;
+    if (P.P > 0) {  // walk the custom pool; without one the env keeps restarting from its own slot
+      int nxt = cursor - s.E + P.stride;
+      P.cursor[m.ee] = s.E + (nxt >= P.P ? nxt % P.P : nxt);
+    }
+  }
+}
+
+template <int GS, int T>
+__global__ __launch_bounds__(EBC_WAVE, EBC_STEP_WAVES(GS)) void orca_step2_kernel(
+    unsigned env1_blocks, unsigned orca_blocks, int hot_E, int hot_N, unsigned hot_magic, unsigned hot_shift,
+    const float4 *hot_tile, const int *hot_n_humans, unsigned hot_epoch, unsigned hot_pad0, unsigned hot_pad1, unsigned hot_pad2,
+    EbcParams p_in, DevState s_in, StepIO io_in, Step2Grid g) {
+  const WaveTrace wt(2);
+  __shared__ __align__(16) Step2Lds<GS> L;
+  const int lane = threadIdx.x;
+  unsigned b = blockIdx.x;
+#ifndef EBC_STEP2_ROLES  // register-budget experiments: compile a subset of the roles
+#define EBC_STEP2_ROLES 7
+#endif
+  if (b < env1_blocks) {
+    __builtin_amdgcn_s_setprio(EBC_ENV_PRIO);  // everything else in the launch waits for these few waves
+    if (EBC_STEP2_ROLES & 1) env1_role(p_in, s_in, io_in, L, b, hot_epoch, lane);
+    return;
+  }
+  b -= env1_blocks;
+  if (b < orca_blocks) {
+    const OrcaHot hot{hot_E, hot_N, hot_magic, hot_shift, hot_tile, hot_n_humans};
+    if (EBC_STEP2_ROLES & 2) orca_role2<GS, T>(p_in, s_in, io_in, hot, hot_epoch, L, b, lane);
+    return;
+  }
+  b -= orca_blocks;
+  if (EBC_STEP2_ROLES & 4) env2_role<T>(p_in, s_in, io_in, L, b, g.epoch, lane);
 }
 
 // SceneGenerator.generate_random_scene for n seeds, one lane per scene (ebc_scene_gen.h): `d` holds the base of

@@ -183,7 +183,13 @@ __device__ __forceinline__ int lp2_group(const Line4 &own, int j, const float4 *
 // as rvo2 holds it); valid = that other exists.  dist_lds: OrcaShape::DIST floats; lines_lds,
 // segs_lds, proj_lds: OrcaShape::LINES float4 each, private to the group.  All lanes return the
 // same (out_x, out_y).
-template <int GS>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// `after_rank`: called once by every lane after the ranking phase (the second form of the step parks loads it
+// issued at the wave's start there: they have had the ranking's time to come back).
+template <int GS, typename Hook = NoHook>
 __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group, bool valid,
                                            float posx, float posy, float velx, float vely,
                                            float radius, float maxSpeed, float prefx, float prefy,
@@ -191,7 +197,7 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
                                            float *dist_lds, float4 *lines_lds, float4 *segs_lds,
                                            float4 *proj_lds, int max_others, float rangeSq,
                                            float invTimeHorizon, float invTimeStep, float &out_x,
-                                           float &out_y) {
+                                           float &out_y, Hook after_rank = Hook()) {
   const int maxN = p.orca_max_neighbors < EBC_MAXNB ? p.orca_max_neighbors : EBC_MAXNB;
 
   // Agent::insertAgentNeighbor: in range, ascending distSq, stable -> rank by counting
@@ -232,6 +238,7 @@ __device__ __forceinline__ void orca_group(const EbcParams &p, int j, int group,
     }
   }
   EBC_MARK(1);
+  after_rank();
   const bool included = inRange && rank < maxN;
   const int nn = __popc(group_ballot<GS>(included, group));
 

@@ -11,8 +11,8 @@
 #include <utility>
 #include <vector>
 
+#include "ebc_host.h"
 #include "ebc_kernels.h"
-#include "ebc_value_net.h"
 
 namespace {
 
@@ -20,20 +20,8 @@ using ebc::DevState;
 using ebc::LookIO;
 using ebc::StepIO;
 
-// ------------------------------------------------------------------------------ host
-thread_local std::string g_err;
-
-int fail(int code, const std::string &msg) {
-  g_err = msg;
-  return code;
-}
-
-#define HIP_TRY(x)                                                                          \
-  do {                                                                                      \
-    hipError_t err__ = (x);                                                                 \
-    if (err__ != hipSuccess)                                                                \
-      return fail(EBC_ERR_DEVICE, std::string(#x) + ": " + hipGetErrorString(err__));       \
-  } while (0)
+using ebc_host::fail;
+using ebc_host::g_err;
 
 struct Handle {
   int device = 0;
@@ -49,6 +37,7 @@ struct Handle {
   ebc::RobotSim robot_sim = {nullptr, nullptr, nullptr};  // ebc_robot_orca_sim: the demonstrator's persistent rvo2 simulators
   bool faulted = false;  // a mailbox wait timed out and was reported: only ebc_reset re-arms the handle
   int orca_gs = 16;  // lanes per human of the ORCA waves
+  int step_form = 3;  // the fused ORCA step: 3 = four roles, ENV with four lanes per env (default); 1 = ENV with a lane per human slot (rounds 1-2); 2 = orca_step2_kernel (experiment: ORCA groups commit their own human)
   unsigned epoch = 0;  // fused ORCA steps launched so far (StepGrid::epoch)
   std::vector<void *> pool_allocs;   // pool arrays (re-allocated by ebc_set_scene_pool)
   uint64_t *pool_grid_alloc = nullptr;
@@ -96,6 +85,9 @@ int arm_mailboxes(Handle *h) {
   HIP_TRY(hipMemsetAsync(h->s.rows_loaded, 0, E * 4, h->stream));
   HIP_TRY(hipMemsetAsync(h->s.robot_ready, 0, E * 4, h->stream));
   HIP_TRY(hipMemsetAsync(h->s.fault, 0, 4, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.frame, 0, E * 64, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.ract, 0, E * 64, h->stream));
+  HIP_TRY(hipMemsetAsync(h->s.committed, 0, EN * 4, h->stream));
   return EBC_OK;
 }
 
@@ -161,6 +153,10 @@ int orca_blocks(const Handle *h) {
 int launch_orca(Handle *h) {
   const int blocks = orca_blocks(h);
 #define OK_(GS) hipLaunchKernelGGL((ebc::orca_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s)
+#ifdef EBC_DEV_GS  // quick development builds: one group size, one row width (make dev)
+  if (h->orca_gs != EBC_DEV_GS) return fail(EBC_ERR_UNSUPPORTED, "development build: one ORCA group size only");
+  OK_(EBC_DEV_GS);
+#else
   switch (h->orca_gs) {
     case 2: OK_(2); break;
     case 3: OK_(3); break;
@@ -176,6 +172,7 @@ int launch_orca(Handle *h) {
     case 21: OK_(21); break;
     default: OK_(32); break;
   }
+#endif
 #undef OK_
   HIP_TRY(hipGetLastError());
   return EBC_OK;
@@ -198,26 +195,90 @@ int launch_orca_step_gs(Handle *h, const StepIO &io, unsigned blocks, const ebc:
   if (h->T == 17)
     hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 17>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream,
                        g.env_blocks, g.orca_blocks, h->s.E, h->s.N, h->s.n_magic, h->s.n_shift, (const float4 *)h->s.tile,
-                       (const int *)h->s.n_humans, h->s.vel, g.epoch, 0u, h->p, h->s, io, g);
+                       (const int *)h->s.n_humans, h->s.vel, g.epoch, h->step_form == 3 ? 1u : 0u, h->p, h->s, io, g);
   else
     hipLaunchKernelGGL((ebc::orca_step_kernel<GS, 13>), dim3((blocks + EBC_STEP_WPB - 1) / EBC_STEP_WPB), dim3(EBC_WAVE * EBC_STEP_WPB), 0, h->stream,
                        g.env_blocks, g.orca_blocks, h->s.E, h->s.N, h->s.n_magic, h->s.n_shift, (const float4 *)h->s.tile,
-                       (const int *)h->s.n_humans, h->s.vel, g.epoch, 0u, h->p, h->s, io, g);
+                       (const int *)h->s.n_humans, h->s.vel, g.epoch, h->step_form == 3 ? 1u : 0u, h->p, h->s, io, g);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
 
 int launch_orca_step_sized(Handle *h, const StepIO &io, unsigned blocks, const ebc::StepGrid &g);
 
+template <int GS>
+int launch_orca_step2_gs(Handle *h, const StepIO &io, const ebc::Step2Grid &g) {
+  if (h->T == 17)
+    hipLaunchKernelGGL((ebc::orca_step2_kernel<GS, 17>), dim3(g.total), dim3(EBC_WAVE), 0, h->stream, g.env1_blocks, g.orca_blocks,
+                       h->s.E, h->s.N, h->s.n_magic, h->s.n_shift, (const float4 *)h->s.tile, (const int *)h->s.n_humans, g.epoch,
+                       0u, 0u, 0u, h->p, h->s, io, g);
+  else
+    hipLaunchKernelGGL((ebc::orca_step2_kernel<GS, 13>), dim3(g.total), dim3(EBC_WAVE), 0, h->stream, g.env1_blocks, g.orca_blocks,
+                       h->s.E, h->s.N, h->s.n_magic, h->s.n_shift, (const float4 *)h->s.tile, (const int *)h->s.n_humans, g.epoch,
+                       0u, 0u, 0u, h->p, h->s, io, g);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+
+// The second form of the fused step (ebc_kernels.h: orca_step2_kernel): ENV1 (lane = env), ORCA (commits its human),
+// ENV2 (lane = human slot).  The launch leaves the humans' next positions / velocities / float tile and the robots'
+// next state in the second buffers: they are the current ones from here on.
+int launch_orca_step2(Handle *h, const StepIO &io) {
+  const int epb = EBC_WAVE / h->s.N;
+  ebc::Step2Grid g;
+  g.env1_blocks = (unsigned)((h->s.E + EBC_WAVE - 1) / EBC_WAVE);
+  g.orca_blocks = (unsigned)orca_blocks(h);
+  g.env2_blocks = (unsigned)((h->s.E + epb - 1) / epb);
+  const unsigned long long blocks = (unsigned long long)g.env1_blocks + g.orca_blocks + g.env2_blocks;
+  if (blocks >= 2147483648ull) return fail(EBC_ERR_UNSUPPORTED, "ORCA step grid >= 2^31 workgroups");
+  if (++h->epoch == 0) h->epoch = 1;
+  g.epoch = h->epoch;
+  g.total = (unsigned)blocks;
+  int rc;
+#ifdef EBC_DEV_GS
+  if (h->orca_gs != EBC_DEV_GS) return fail(EBC_ERR_UNSUPPORTED, "development build: one ORCA group size only");
+  rc = launch_orca_step2_gs<EBC_DEV_GS>(h, io, g);
+#else
+  switch (h->orca_gs) {
+    case 2: rc = launch_orca_step2_gs<2>(h, io, g); break;
+    case 3: rc = launch_orca_step2_gs<3>(h, io, g); break;
+    case 4: rc = launch_orca_step2_gs<4>(h, io, g); break;
+    case 5: rc = launch_orca_step2_gs<5>(h, io, g); break;
+    case 6: rc = launch_orca_step2_gs<6>(h, io, g); break;
+    case 7: rc = launch_orca_step2_gs<7>(h, io, g); break;
+    case 8: rc = launch_orca_step2_gs<8>(h, io, g); break;
+    case 9: rc = launch_orca_step2_gs<9>(h, io, g); break;
+    case 10: rc = launch_orca_step2_gs<10>(h, io, g); break;
+    case 12: rc = launch_orca_step2_gs<12>(h, io, g); break;
+    case 16: rc = launch_orca_step2_gs<16>(h, io, g); break;
+    case 21: rc = launch_orca_step2_gs<21>(h, io, g); break;
+    default: rc = launch_orca_step2_gs<32>(h, io, g); break;
+  }
+#endif
+  if (rc == EBC_OK) {
+    std::swap(h->s.robot, h->s.robot_n);
+    std::swap(h->s.px, h->s.px_n);
+    std::swap(h->s.py, h->s.py_n);
+    std::swap(h->s.vx, h->s.vx_n);
+    std::swap(h->s.vy, h->s.vy_n);
+    std::swap(h->s.tile, h->s.tile_n);
+  }
+  return rc;
+}
+
 int launch_orca_step(Handle *h, const StepIO &io) {
+  if (h->step_form == 2) return launch_orca_step2(h, io);
   const int epb = EBC_WAVE / h->s.N;
   const int R = h->s.N + h->s.S;
   ebc::StepGrid g;
-  g.env_blocks = (unsigned)((h->s.E + epb - 1) / epb);
+  const unsigned state_blocks = (unsigned)((h->s.E + epb - 1) / epb);
+  // form 3: the ENV role with four lanes per ENV (16 envs per wave) instead of a lane per human slot
+  constexpr int envs_per_wave3 = EBC_WAVE / EBC_ENV_LANES;
+  g.env_blocks = h->step_form == 3 ? (unsigned)((h->s.E + envs_per_wave3 - 1) / envs_per_wave3) : state_blocks;
   g.orca_blocks = (unsigned)orca_blocks(h);
   g.rows_epw = R <= EBC_WAVE ? (unsigned)(EBC_WAVE / R) : 1u;
   g.rows_blocks = (io.ob || io.obs_rotated) ? (unsigned)((h->s.E + g.rows_epw - 1) / g.rows_epw) : 0u;
-  const unsigned long long blocks = 2ull * g.env_blocks + g.orca_blocks + g.rows_blocks;
+  const unsigned long long blocks = (unsigned long long)g.env_blocks + state_blocks + g.orca_blocks + g.rows_blocks;
   if (blocks >= 2147483648ull) return fail(EBC_ERR_UNSUPPORTED, "ORCA step grid >= 2^31 workgroups");
   if (++h->epoch == 0) h->epoch = 1;  // every mailbox word is tagged with the epoch of the launch that wrote it; 0 = never
   g.epoch = h->epoch;
@@ -229,6 +290,10 @@ int launch_orca_step(Handle *h, const StepIO &io) {
 }
 
 int launch_orca_step_sized(Handle *h, const StepIO &io, unsigned blocks, const ebc::StepGrid &g) {
+#ifdef EBC_DEV_GS
+  if (h->orca_gs != EBC_DEV_GS) return fail(EBC_ERR_UNSUPPORTED, "development build: one ORCA group size only");
+  return launch_orca_step_gs<EBC_DEV_GS>(h, io, blocks, g);
+#else
   switch (h->orca_gs) {
     case 2: return launch_orca_step_gs<2>(h, io, blocks, g);
     case 3: return launch_orca_step_gs<3>(h, io, blocks, g);
@@ -244,6 +309,7 @@ int launch_orca_step_sized(Handle *h, const StepIO &io, unsigned blocks, const e
     case 21: return launch_orca_step_gs<21>(h, io, blocks, g);
     default: return launch_orca_step_gs<32>(h, io, blocks, g);
   }
+#endif
 }
 
 int launch_step(Handle *h, const StepIO &io, int policy) {
@@ -464,6 +530,8 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
   A_(tile, EN * 2);
   A_(done, n_envs); A_(hact, EN * 2);
   A_(vel, EN); A_(env_done, n_envs); A_(rows_loaded, n_envs); A_(robot_ready, n_envs); A_(fault, 1);  // zeroed: tag 0 = no launch
+  A_(px_n, EN); A_(py_n, EN); A_(vx_n, EN); A_(vy_n, EN); A_(tile_n, EN * 2);
+  A_(frame, (size_t)n_envs * 4); A_(ract, (size_t)n_envs * 4); A_(committed, EN);
 #undef A_
   if (rc == EBC_OK) rc = dev_alloc(h, &s.pool.cursor, n_envs);
   if (rc == EBC_OK) rc = dev_alloc(h, &s.grid_scene, n_envs);
@@ -486,6 +554,8 @@ int ebc_create(int device_id, int n_envs, int max_humans, int max_static, const 
     static const int sizes[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32};
     for (int g : sizes)
       if (g >= others) { h->orca_gs = g; break; }
+    const char *form = getenv("EBCSIM_STEP_FORM");  // measurements only: 1 = the four-role launch of rounds 1-2
+    if (form && atoi(form) >= 1 && atoi(form) <= 3) h->step_form = atoi(form);
     const char *force = getenv("EBCSIM_ORCA_GROUP");  // measurements only: a larger group size
     if (force && atoi(force) >= h->orca_gs)
       for (int g : sizes)
@@ -802,6 +872,10 @@ int launch_robot_orca(Handle *h, double safety_space, double *d_act) {
   const int epw = EBC_WAVE / gs;
   const unsigned blocks = (unsigned)((h->s.E + epw - 1) / epw);
 #define RK_(GS) hipLaunchKernelGGL((ebc::orca_robot_kernel<GS>), dim3(blocks), dim3(EBC_WAVE), 0, h->stream, h->p, h->s, safety_space, d_act, h->robot_sim)
+#ifdef EBC_DEV_GS
+  if (gs != 21) return fail(EBC_ERR_UNSUPPORTED, "development build: robot ORCA for 21-lane groups only");
+  RK_(21);
+#else
   switch (gs) {
     case 2: RK_(2); break;
     case 3: RK_(3); break;
@@ -817,6 +891,7 @@ int launch_robot_orca(Handle *h, double safety_space, double *d_act) {
     case 21: RK_(21); break;
     default: RK_(32); break;
   }
+#endif
 #undef RK_
   HIP_TRY(hipGetLastError());
   return EBC_OK;
@@ -1192,279 +1267,6 @@ int ebc_timing_read(void *handle, int reset, double *avg_ms, int64_t *launches) 
 
 }  // extern "C"
 
-// ------------------------------------------------------------------------- value-network layers
-namespace {
-
-uint16_t bf16_rn(float v) {  // round to nearest even, as v_cvt_pk_bf16_f32
-  uint32_t u;
-  memcpy(&u, &v, 4);
-  if ((u & 0x7f800000u) == 0x7f800000u) return (uint16_t)(u >> 16);  // inf / nan
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-float bf16_to_float(uint16_t b) {
-  const uint32_t u = (uint32_t)b << 16;
-  float v;
-  memcpy(&v, &u, 4);
-  return v;
-}
-
-struct Mlp2 {
-  int device = 0, K0 = 0, H = 0, O = 0;
-  ebc::PackedLayer L1{}, L2{};
-  float *final_w = nullptr;  // optional third layer with one output
-  float final_b = 0.0f;
-  std::vector<void *> allocs;
-};
-
-// W [out][in] (torch Linear layout) -> A fragments of mfma_f32_32x32x16_bf16, split in hi / lo.
-// acc_order: the layer's input is an accumulator tile of the layer before (fragment element j of lane
-// half h in k-step s is row 16 s + 8 (j >> 2) + 4 h + (j & 3)); otherwise natural order 16 s + 8 h + j.
-int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool acc_order, ebc::PackedLayer *L) {
-  const int To = (out + 31) / 32, Ti = (in + 31) / 32;
-  std::vector<uint16_t> frag((size_t)To * Ti * 2 * 2 * 64 * 8);
-  for (int t = 0; t < To; ++t)
-    for (int u = 0; u < Ti; ++u)
-      for (int s = 0; s < 2; ++s)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 8; ++j) {
-            const int i = lane & 31, hh = lane >> 5;
-            const int k = acc_order ? 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3) : 16 * s + 8 * hh + j;
-            const int row = t * 32 + i, colk = u * 32 + k;
-            const float v = (row < out && colk < in) ? W[(size_t)row * in + colk] : 0.0f;
-            const uint16_t hi = bf16_rn(v), lo = bf16_rn(v - bf16_to_float(hi));
-            const size_t base = ((((size_t)t * Ti + u) * 2 + s) * 2) * 64 * 8;
-            frag[base + (size_t)lane * 8 + j] = hi;
-            frag[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
-          }
-  std::vector<float> bias((size_t)To * 2 * 16, 0.0f);
-  for (int t = 0; t < To; ++t)
-    for (int hh = 0; hh < 2; ++hh)
-      for (int r = 0; r < 16; ++r) {
-        const int unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (unit < out) bias[((size_t)t * 2 + hh) * 16 + r] = b[unit];
-      }
-  void *df = nullptr, *db = nullptr;
-  HIP_TRY(hipMalloc(&df, frag.size() * 2));
-  m->allocs.push_back(df);
-  HIP_TRY(hipMalloc(&db, bias.size() * 4));
-  m->allocs.push_back(db);
-  HIP_TRY(hipMemcpy(df, frag.data(), frag.size() * 2, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
-  L->frag = (const uint4 *)df;
-  L->bias = (const float *)db;
-  L->in_tiles = Ti;
-  L->out_tiles = To;
-  return EBC_OK;
-}
-
-template <int TI, int TO, int NW, int LEAN, int KIN>
-int launch_mlp2_kin(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
-  const size_t weights = LEAN == 2 ? (size_t)(TI + TO) * 4096 : LEAN ? (size_t)(2 * TI + TO) * 4096 : 2 * (size_t)(TI + TO) * 4096;
-  const size_t lds = (weights + 31) / 32 * 32 + (size_t)m->L1.out_tiles * 32 * 4 +
-                     (ex.row_bias ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0);  // + the waves' parked group terms
-  static size_t raised_dev[64][2] = {{0}};  // more than the 64 KB a launch gets by default; a function attribute is per device
-  size_t &raised = raised_dev[m->device & 63][ex.row_bias ? 1 : 0];
-  if (lds > 65536 && lds > raised) {
-    if (ex.row_bias)
-      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN, KIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else
-      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_split_wg_kernel<TI, TO, NW, false, LEAN, KIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    raised = lds;
-  }
-  constexpr int rows = 32 * NW;
-  {  // the row-group sums live in the coalesced-output epilogue (ebc_value_net.h): the block must be one that takes it
-    constexpr size_t a_size = (size_t)TI * 256, b_size = (size_t)TO * 256;
-    constexpr size_t per_u = LEAN == 2 ? (a_size + b_size + 1) / 2 : LEAN ? (2 * a_size + b_size + 1) / 2 : a_size + b_size;
-    if (ex.partial && !((m->O & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= per_u * 2 * 16))
-      return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_reduce: this block shape has no tile epilogue");
-  }
-  const dim3 grid((unsigned)((M + rows - 1) / rows)), block(64 * NW);
-  if (ex.row_bias)
-    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, true, LEAN, KIN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
-  else
-    hipLaunchKernelGGL((ebc::mlp2_split_wg_kernel<TI, TO, NW, false, LEAN, KIN>), grid, block, lds, st, x, M, m->K0, m->L1, m->L2, relu_out, y, m->O, ex);
-  HIP_TRY(hipGetLastError());
-  return EBC_OK;
-}
-
-// 200-wide inputs (the h1 rows of mlp2 and of the attention stack) end in the first half of their seventh tile
-template <int TI, int TO, int NW, int LEAN>
-int launch_mlp2_shape(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
-  if constexpr (TI == 7) {
-    if (m->K0 <= 32 * TI - 16) return launch_mlp2_kin<TI, TO, NW, LEAN, 1>(m, st, x, M, relu_out, y, ex);
-  }
-  return launch_mlp2_kin<TI, TO, NW, LEAN, 0>(m, st, x, M, relu_out, y, ex);
-}
-
-template <int TI, int TO>
-int launch_mlp2_to(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
-  // Workgroup shape by LDS: the full layout (both halves of the weights double-buffered) twice per CU where it
-  // fits (4 waves each); else the lean layout (one slot for the L2 halves) twice per CU where THAT fits: two
-  // independent 4-wave workgroups fill each other's waits, which one lock-stepped 8-wave workgroup cannot; else
-  // 8 waves sharing one full layout (two waves per SIMD with 256 registers each: measured faster than 4 waves
-  // with 512 for the widest shape, spills included).
-  constexpr size_t full = 2 * (size_t)(TI + TO) * 4096, lean = (size_t)(2 * TI + TO) * 4096, half_cu = 78 * 1024;
-#ifdef EBC_MLP_NO_LEAN
-  constexpr bool use_lean = false;
-#else
-  constexpr bool use_lean = full > half_cu && lean <= half_cu;
-#endif
-  if (use_lean) return launch_mlp2_shape<TI, TO, 4, 1>(m, st, x, M, relu_out, y, ex);
-#ifdef EBC_MLP_LEAN2  // A/B: one slot per half for shapes whose lean layout does not fit twice (7 + 7 tiles)
-  constexpr size_t lean2 = (size_t)(TI + TO) * 4096;
-  if (full > half_cu && lean2 + 16 * 1024 <= half_cu) return launch_mlp2_shape<TI, TO, 4, 2>(m, st, x, M, relu_out, y, ex);
-#endif
-  return launch_mlp2_shape<TI, TO, (full > 80 * 1024 ? 8 : 4), 0>(m, st, x, M, relu_out, y, ex);
-}
-
-template <int TI>
-int launch_mlp2(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
-  switch (m->L2.out_tiles) {
-    case 1: return launch_mlp2_to<TI, 1>(m, st, x, M, relu_out, y, ex);
-    case 2: return launch_mlp2_to<TI, 2>(m, st, x, M, relu_out, y, ex);
-    case 3: return launch_mlp2_to<TI, 3>(m, st, x, M, relu_out, y, ex);
-    case 4: return launch_mlp2_to<TI, 4>(m, st, x, M, relu_out, y, ex);
-    case 5: return launch_mlp2_to<TI, 5>(m, st, x, M, relu_out, y, ex);
-    case 6: return launch_mlp2_to<TI, 6>(m, st, x, M, relu_out, y, ex);
-    case 7: return launch_mlp2_to<TI, 7>(m, st, x, M, relu_out, y, ex);
-    default: return fail(EBC_ERR_UNSUPPORTED, "mlp2: more than 224 outputs");
-  }
-}
-
-int mlp2_dispatch(const Mlp2 *m, hipStream_t st, const float *x, int M, int relu_out, float *y, const ebc::MlpExtra &ex) {
-  switch (m->L1.in_tiles) {
-    case 1: return launch_mlp2<1>(m, st, x, M, relu_out, y, ex);
-    case 2: return launch_mlp2<2>(m, st, x, M, relu_out, y, ex);
-    case 3: return launch_mlp2<3>(m, st, x, M, relu_out, y, ex);
-    case 4: return launch_mlp2<4>(m, st, x, M, relu_out, y, ex);
-    case 5: return launch_mlp2<5>(m, st, x, M, relu_out, y, ex);
-    case 6: return launch_mlp2<6>(m, st, x, M, relu_out, y, ex);
-    default: return launch_mlp2<7>(m, st, x, M, relu_out, y, ex);
-  }
-}
-
-}  // namespace
-
-extern "C" {
-
-int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
-                    const float *b2, const float *w3, const float *b3, void **out) {
-  if (!w1 || !b1 || !w2 || !b2 || !out) return fail(EBC_ERR_INVALID, "null argument");
-  if (K0 <= 0 || H <= 0 || O <= 0 || K0 > 224 || O > 224) return fail(EBC_ERR_UNSUPPORTED, "mlp2 dimensions");
-  int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
-    return fail(EBC_ERR_DEVICE, "no HIP device: libebcsim has no CPU fallback");
-  if (device_id < 0 || device_id >= count) return fail(EBC_ERR_INVALID, "device_id out of range");
-  HIP_TRY(hipSetDevice(device_id));
-  Mlp2 *m = new Mlp2();
-  m->device = device_id; m->K0 = K0; m->H = H; m->O = O;
-  int rc = pack_layer(m, w1, b1, H, K0, false, &m->L1);
-  if (rc == EBC_OK) rc = pack_layer(m, w2, b2, O, H, true, &m->L2);
-  if (rc == EBC_OK && w3) {
-    void *dw = nullptr;
-    if (hipMalloc(&dw, (size_t)O * 4) != hipSuccess || hipMemcpy(dw, w3, (size_t)O * 4, hipMemcpyHostToDevice) != hipSuccess)
-      rc = fail(EBC_ERR_DEVICE, "mlp2: third layer upload failed");
-    if (dw) m->allocs.push_back(dw);
-    m->final_w = (float *)dw;
-    m->final_b = b3 ? b3[0] : 0.0f;
-  }
-  if (rc != EBC_OK) {
-    for (void *ptr : m->allocs) (void)hipFree(ptr);
-    delete m;
-    return rc;
-  }
-  *out = m;
-  return EBC_OK;
-}
-
-int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
-                     int group_rows, float *y) {
-  Mlp2 *m = (Mlp2 *)mlp;
-  if (!m || !x || !y || M < 0) return fail(EBC_ERR_INVALID, "mlp2 forward arguments");
-  if (row_bias && group_rows <= 0) return fail(EBC_ERR_INVALID, "mlp2: group_rows");
-  if (M == 0) return EBC_OK;
-  HIP_TRY(hipSetDevice(m->device));
-  hipStream_t st = (hipStream_t)stream;
-  const ebc::MlpExtra ex = {row_bias, group_rows, m->H, m->final_w, m->final_b, nullptr, nullptr, 0, 1};
-  return mlp2_dispatch(m, st, x, M, relu_out, y, ex);
-}
-
-int ebc_mlp2_forward_reduce(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
-                            int group_rows, float *y, int seg_rows, const float *row_weight, double *partial) {
-  Mlp2 *m = (Mlp2 *)mlp;
-  if (!m || !x || !partial || M < 0) return fail(EBC_ERR_INVALID, "mlp2 forward_reduce arguments");
-  if (row_bias && group_rows <= 0) return fail(EBC_ERR_INVALID, "mlp2: group_rows");
-  if (m->final_w) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_reduce: a block with a one-output third layer has no [M][O] rows");
-  if (seg_rows < 16) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_reduce: groups of fewer than 16 rows (a tile would touch more than three)");
-  if (m->O & 3) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_reduce: O must be a multiple of 4");
-  if (M == 0) return EBC_OK;
-  HIP_TRY(hipSetDevice(m->device));
-  const ebc::MlpExtra ex = {row_bias, group_rows, m->H, nullptr, 0.0f, row_weight, partial, seg_rows, y ? 1 : 0};
-  return mlp2_dispatch(m, (hipStream_t)stream, x, M, relu_out, y, ex);
-}
-
-int ebc_pair_weights(void *stream, const float *scores, const long long *n_valid, int B, int R, float *w) {
-  if (!scores || !w || B < 0 || R <= 0) return fail(EBC_ERR_INVALID, "pair_weights arguments");
-  if (B == 0) return EBC_OK;
-  hipLaunchKernelGGL(ebc::pair_weights_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores, n_valid, B, R, w);
-  HIP_TRY(hipGetLastError());
-  return EBC_OK;
-}
-
-int ebc_pair_mask(void *stream, const long long *n_valid, int B, int R, float *w) {
-  if (!n_valid || !w || B < 0 || R <= 0) return fail(EBC_ERR_INVALID, "pair_mask arguments");
-  if (B == 0) return EBC_OK;
-  const size_t n = (size_t)B * R;
-  hipLaunchKernelGGL(ebc::pair_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n_valid, B, R, w);
-  HIP_TRY(hipGetLastError());
-  return EBC_OK;
-}
-
-int ebc_pair_combine(void *stream, const double *partial, const long long *n_valid, int B, int R, int O, int mean, float *out) {
-  if (!partial || !out || B < 0 || R < 16 || R > 32 || O <= 0) return fail(EBC_ERR_INVALID, "pair_combine arguments (16 <= R <= 32)");
-  if ((O & 3) || (((size_t)partial | (size_t)out) & 15)) return fail(EBC_ERR_INVALID, "pair_combine: O a multiple of 4, 16-byte aligned buffers");
-  if (B == 0) return EBC_OK;
-  hipLaunchKernelGGL(ebc::pair_combine_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, partial, n_valid, B, R, O,
-                     mean, out);
-  HIP_TRY(hipGetLastError());
-  return EBC_OK;
-}
-
-int ebc_pair_mean(void *stream, const float *h, const long long *n_valid, int B, int R, int H, float *g) {
-  if (!h || !g || B < 0 || R <= 0 || H <= 0) return fail(EBC_ERR_INVALID, "pair_mean arguments");
-  if (B == 0) return EBC_OK;
-  if (((size_t)h | (size_t)g) & 15 || (H & 3)) {
-    if (H & 3) return fail(EBC_ERR_UNSUPPORTED, "pair_mean: H must be a multiple of 4");
-    return fail(EBC_ERR_INVALID, "pair_mean: 16-byte aligned buffers");
-  }
-  hipLaunchKernelGGL(ebc::pair_mean_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, n_valid, B, R, H, g);
-  HIP_TRY(hipGetLastError());
-  return EBC_OK;
-}
-
-int ebc_pair_attend(void *stream, const float *scores, const float *feat, const long long *n_valid, int B, int R, int F,
-                    float *out) {
-  if (!scores || !feat || !out || B < 0 || R <= 0 || F <= 0) return fail(EBC_ERR_INVALID, "pair_attend arguments");
-  if (B == 0) return EBC_OK;
-  if ((F & 3) || F > 256) return fail(EBC_ERR_UNSUPPORTED, "pair_attend: F must be a multiple of 4, at most 256");
-  if (((size_t)feat | (size_t)out) & 15) return fail(EBC_ERR_INVALID, "pair_attend: 16-byte aligned buffers");
-  hipLaunchKernelGGL(ebc::pair_attend_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, scores, feat,
-                     n_valid, B, R, F, out);
-  HIP_TRY(hipGetLastError());
-  return EBC_OK;
-}
-
-int ebc_mlp2_destroy(void *mlp) {
-  Mlp2 *m = (Mlp2 *)mlp;
-  if (!m) return EBC_OK;
-  for (void *ptr : m->allocs) (void)hipFree(ptr);
-  delete m;
-  return EBC_OK;
-}
-
-}  // extern "C"
-
 #ifdef EBC_WAVE_TRACE
 // tools only (libebcsim_trace.so): where the kernels leave their wave timeline, [4][blocks][EBC_TRACE_ROW] u64
 extern "C" int ebc_debug_wave_trace(void *device_buffer, unsigned blocks) {
@@ -1475,6 +1277,13 @@ extern "C" int ebc_debug_wave_trace(void *device_buffer, unsigned blocks) {
 }
 // tests only: from the next fused ORCA step on, the ORCA group of flat human index `human` (e * N + i) does
 // not publish its velocity, so its consumers run into EBC_SPIN_LIMIT (lowered in this build); -1 = off
+// tests / debugging only: the hand-off records of the second step form, copied to the host
+extern "C" int ebc_debug_read(void *handle, int which, void *dst, size_t bytes) {
+  Handle *h = (Handle *)handle;
+  const void *src = which == 0 ? (const void *)h->s.frame : which == 1 ? (const void *)h->s.ract : (const void *)h->s.committed;
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? EBC_OK : EBC_ERR_DEVICE;
+}
 extern "C" int ebc_debug_withhold(int human) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(ebc::g_withhold_human), &human, sizeof(human)) != hipSuccess) return EBC_ERR_DEVICE;
   return EBC_OK;

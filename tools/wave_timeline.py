@@ -62,6 +62,9 @@ def main():
             continue
         if tag == 2:  # orca_step_kernel: blocks in role order ENV, ORCA, ROWS, STATE
             env_blocks = -(-E // (64 // batch.N))
+            state_blocks = env_blocks
+            if os.environ.get("EBCSIM_STEP_FORM") == "3":  # the ENV role with a lane per env
+                env_blocks = -(-E // 16)
             others = batch.N - 1 + (1 if params.robot_visible else 0)
             gs = next(g for g in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32) if g >= others)
             orca_blocks = -(-E * batch.N // (64 // gs))
@@ -79,7 +82,7 @@ def main():
         for name, sel in parts:
             if sel.any():
                 report(np, name, rows[sel], launch0 if tag == 3 and launch0 is not None else base_all)
-        if tag == 2 and len(idx) == b3 + env_blocks:
+        if tag == 2 and len(idx) == b3 + state_blocks and state_blocks == env_blocks:
             # what each STATE wave waited for: the ORCA waves of its envs and its ENV wave
             end = (rows[:, 1].astype(np.int64) - base_all) / 100.0
             start = (rows[:, 0].astype(np.int64) - base_all) / 100.0
