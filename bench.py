@@ -340,7 +340,7 @@ def also_kernels(env, batch, dev, cfg_s=None):
     try:
         # One robot decision per env for 1024 envs: 81-action look-ahead sweep + the SARL value network (the
         # architecture of the reference's shipped eb-cadrl weights, data/eb-cadrl/policy_x2_agent_type.config;
-        # random-init weights) on 1024 x 81 pairs x R rows + top-2 refinement + argmax
+        # random-init weights) on 1024 x 81 pairs x R rows + float32 refinement of the near-best candidates + argmax
         # (rl/policy/multi_human_rl.py:38-80, rl/policy/sarl.py:38-82)
         from ebcsim.batched import BatchedEnv
         from ebcsim.sarl import DeviceSarlPolicy, SarlValueNet
@@ -364,9 +364,9 @@ def also_kernels(env, batch, dev, cfg_s=None):
         macs = float(Ed) * A * (R * row_macs + pair_macs)
         tf = 3.0 * 2.0 * macs / (ms * 1e-3) / 1e12  # three bf16 MFMA products per float32 product
         out.append({"kernel": "decision: %d envs x %d actions x %d rows, look-ahead sweep + SARL x2 network (split-bf16 MFMA "
-                              "blocks with the pair mean / attention sum in their epilogues) + top-2 float32 refinement + argmax" % (Ed, A, R),
+                              "blocks with the pair mean / attention sum in their epilogues) + float32 re-evaluation (ebc_mlp2_forward_f32) of every candidate within the blocks' error bound of the best + argmax" % (Ed, A, R),
                     "ms_per_decision_batch": ms, "decisions_per_s": Ed / (ms * 1e-3),
-                    "native_blocks": bool(net._native_blocks()),
+                    "native_blocks": bool(net._native_blocks()), "refine_stats": getattr(net, "refine_stats", None),
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": tf / MFMA_BF16_PEAK_TFLOPS, "f32_equivalent_tflops": tf / 3.0,
                                  "algorithmic_macs_per_batch": macs}})
@@ -470,10 +470,18 @@ def main():
         env = None
         step = lambda: None  # noqa: E731
 
+    def group_barrier():
+        # a rehearsal's barrier is an all-reduce of a CPU scalar: dist.barrier() on a gloo group picks a device for
+        # itself and initialises HIP in ranks that were to stay off the card (seen: the box's process guard counted them)
+        if rehearsal:
+            dist.all_reduce(torch.zeros(1))
+        else:
+            dist.barrier()
+
     def barrier():
         gpu_sync()
         if collective:
-            dist.barrier()
+            group_barrier()
         gpu_sync()
 
     for _ in range(args.warmup):
@@ -616,7 +624,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(params, batch)
         print(json.dumps(line), flush=True)
     if collective:
-        dist.barrier()
+        group_barrier()
         dist.destroy_process_group()
 
 

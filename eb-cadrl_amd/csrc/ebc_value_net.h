@@ -646,4 +646,191 @@ __global__ __launch_bounds__(256) void pair_attend_kernel(const float *scores, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same two-layer block in plain float32 on the vector ALUs (ebc_mlp2_forward_f32): every product an fmaf into a
+// float32 sum, like a float32 GEMM.  For the FEW rows whose value decides an argmax (SarlValueNet.action_values
+// re-evaluates the candidates within the split-bf16 error of the best one): at ~2 % of the rows its speed does not
+// matter, its accuracy does — and the refinement no longer leaves the library for ~11 small hipBLASLt GEMMs and ~20
+// element-wise launches.  16 rows per 256-thread workgroup; lane = output unit (mod 64), wave = 4 of the 16 rows; the
+// input tile and the hidden tile wait transposed in LDS (read as broadcast float4: all lanes of a wave want the same
+// four rows), weights are read transposed [K][units padded to 64] so that a wave's loads are contiguous.
+struct F32Layer {
+  const float *wt;  // [in][out_pad]
+  const float *b;   // [out_pad]
+  int in, out, out_pad;
+};
+#define EBC_F32_ROWS 16
+#define EBC_F32_MAXU 5  // units of a layer <= 64 * this (the padded width of the transposed weights)
+
+// thread t owns output unit t for all 16 rows of the tile (every weight is loaded by exactly one thread of the
+// workgroup); units 256.. (a 300-wide layer has 44 of them) are shared out as (unit 256 + lane, four rows per wave).
+// Two-level sums (32 products at a time into a partial sum, the partial sums into the total): the rounding error of a
+// 300-term dot product stays at the level of a blocked GEMM's instead of growing with one long chain.
+struct F32Acc {
+  float main[EBC_F32_ROWS];
+  float extra[4];
+};
+__device__ __forceinline__ void f32_layer(const F32Layer &L, const float *inT, int t, F32Acc &acc) {
+  const int lane = t & 63, rg = t >> 6;
+  const bool has_main = t < L.out, has_extra = 256 + lane < L.out;
+#pragma unroll
+  for (int r = 0; r < EBC_F32_ROWS; ++r) acc.main[r] = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc.extra[q] = 0.0f;
+  for (int k0 = 0; k0 < L.in; k0 += 32) {
+    F32Acc part;
+#pragma unroll
+    for (int r = 0; r < EBC_F32_ROWS; ++r) part.main[r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) part.extra[q] = 0.0f;
+    const int k1 = min(k0 + 32, L.in);
+    for (int k = k0; k < k1; ++k) {
+      const float4 *xr = reinterpret_cast<const float4 *>(inT + k * EBC_F32_ROWS);
+      const float *w = L.wt + (size_t)k * L.out_pad;
+      if (has_main) {
+        const float wv = w[t];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 x4 = xr[q];
+          part.main[4 * q] = __builtin_fmaf(x4.x, wv, part.main[4 * q]);
+          part.main[4 * q + 1] = __builtin_fmaf(x4.y, wv, part.main[4 * q + 1]);
+          part.main[4 * q + 2] = __builtin_fmaf(x4.z, wv, part.main[4 * q + 2]);
+          part.main[4 * q + 3] = __builtin_fmaf(x4.w, wv, part.main[4 * q + 3]);
+        }
+      }
+      if (has_extra) {
+        const float wv = w[256 + lane];
+        const float4 x4 = xr[rg];
+        part.extra[0] = __builtin_fmaf(x4.x, wv, part.extra[0]);
+        part.extra[1] = __builtin_fmaf(x4.y, wv, part.extra[1]);
+        part.extra[2] = __builtin_fmaf(x4.z, wv, part.extra[2]);
+        part.extra[3] = __builtin_fmaf(x4.w, wv, part.extra[3]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < EBC_F32_ROWS; ++r) acc.main[r] += part.main[r];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc.extra[q] += part.extra[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp2_f32_kernel(const float *x, int M, F32Layer L1, F32Layer L2, int relu_out, float *y,
+                                                       const float *row_bias, int group_rows, const float *final_w,
+                                                       float final_b) {
+  extern __shared__ __align__(16) float f32_lds[];
+  float *xT = f32_lds;                                  // [K0][16]
+  float *hT = f32_lds + (size_t)L1.in * EBC_F32_ROWS;   // [H][16]
+  __shared__ float fin_part[4][EBC_F32_ROWS];
+  const int t = threadIdx.x, lane = t & 63, rg = t >> 6;
+  const int row0 = blockIdx.x * EBC_F32_ROWS;
+  const int K0 = L1.in, H = L1.out, O = L2.out;
+  for (int idx = t; idx < EBC_F32_ROWS * K0; idx += 256) {
+    const int r = idx / K0, k = idx - r * K0;
+    xT[k * EBC_F32_ROWS + r] = row0 + r < M ? x[(size_t)(row0 + r) * K0 + k] : 0.0f;
+  }
+  __syncthreads();
+  F32Acc acc;
+  f32_layer(L1, xT, t, acc);
+  auto hidden = [&](int unit, int r, float a) {
+    const int row = row0 + r;
+    float v = a + L1.b[unit];
+    if (row_bias && row < M) v += row_bias[(size_t)(row / group_rows) * H + unit];
+    hT[unit * EBC_F32_ROWS + r] = v > 0.0f ? v : 0.0f;
+  };
+  if (t < H) {
+#pragma unroll
+    for (int r = 0; r < EBC_F32_ROWS; ++r) hidden(t, r, acc.main[r]);
+  }
+  if (256 + lane < H) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hidden(256 + lane, 4 * rg + q, acc.extra[q]);
+  }
+  __syncthreads();
+  f32_layer(L2, hT, t, acc);
+  float fin[EBC_F32_ROWS];
+#pragma unroll
+  for (int r = 0; r < EBC_F32_ROWS; ++r) fin[r] = 0.0f;
+  auto output = [&](int unit, int r, float a) {
+    const int row = row0 + r;
+    float v = a + L2.b[unit];
+    if (relu_out || final_w) v = v > 0.0f ? v : 0.0f;  // the one-output tail acts on relu(out), like the matrix-core form
+    if (final_w) fin[r] = __builtin_fmaf(final_w[unit], v, fin[r]);
+    else if (row < M) y[(size_t)row * O + unit] = v;
+  };
+  if (t < O) {
+#pragma unroll
+    for (int r = 0; r < EBC_F32_ROWS; ++r) output(t, r, acc.main[r]);
+  }
+  if (256 + lane < O) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      // (fin is indexed by a compile-time row below: add the four rows of this wave's share where they belong)
+      const int unit = 256 + lane, r = 4 * rg + q;
+      float v = acc.extra[q] + L2.b[unit];
+      if (relu_out || final_w) v = v > 0.0f ? v : 0.0f;
+      if (final_w) {
+#pragma unroll
+        for (int rr = 0; rr < EBC_F32_ROWS; ++rr)
+          if (rr == r) fin[rr] = __builtin_fmaf(final_w[unit], v, fin[rr]);
+      } else if (row0 + r < M) {
+        y[(size_t)(row0 + r) * O + unit] = v;
+      }
+    }
+  }
+  if (final_w) {  // the third layer's one output: units are spread over the 256 threads
+#pragma unroll
+    for (int r = 0; r < EBC_F32_ROWS; ++r) {
+      float v = fin[r];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) fin_part[rg][r] = v;
+    }
+    __syncthreads();
+    if (t < EBC_F32_ROWS && row0 + t < M) y[row0 + t] = fin_part[0][t] + fin_part[1][t] + fin_part[2][t] + fin_part[3][t] + final_b;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Re-packing a block from weights that live on the DEVICE (ebc_mlp2_update): the training loop changes the network
+// every round, and its rollouts are decisions like any others — without this they ran on float32 GEMMs because the
+// packed copies were made on the host at creation.  One thread per packed element, the host packer's layout
+// (pack_layer / pack_f32 in ebcsim_value_net.hip) and its rounding (round-to-nearest-even bf16 of v and of v - hi):
+// the fragments come out bit-equal to the host's.
+__device__ __forceinline__ unsigned short bf16_rne_bits(float v) {
+  unsigned u = __float_as_uint(v);
+  if ((u & 0x7f800000u) == 0x7f800000u) return (unsigned short)(u >> 16);  // inf / nan
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__global__ __launch_bounds__(256) void mlp2_pack_kernel(const float *W, const float *b, int out, int in, int acc_order,
+                                                        unsigned short *frag, float *bias, float *wt, float *bt, int out_pad) {
+  const int To = (out + 31) / 32, Ti = (in + 31) / 32;
+  const size_t n_frag = (size_t)To * Ti * 2 * 64 * 8;  // (t, u, s, lane, j): hi and lo written together
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n_frag) {
+    const int j = (int)(q & 7), lane = (int)((q >> 3) & 63), sstep = (int)((q >> 9) & 1);
+    const size_t tu = q >> 10;
+    const int u = (int)(tu % Ti), t = (int)(tu / Ti);
+    const int i = lane & 31, hh = lane >> 5;
+    const int k = acc_order ? 16 * sstep + 8 * (j >> 2) + 4 * hh + (j & 3) : 16 * sstep + 8 * hh + j;
+    const int row = t * 32 + i, colk = u * 32 + k;
+    const float v = (row < out && colk < in) ? W[(size_t)row * in + colk] : 0.0f;
+    const unsigned short hi = bf16_rne_bits(v);
+    const unsigned short lo = bf16_rne_bits(v - __uint_as_float((unsigned)hi << 16));
+    const size_t base = ((((size_t)t * Ti + u) * 2 + sstep) * 2) * 64 * 8;
+    frag[base + (size_t)lane * 8 + j] = hi;
+    frag[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+  }
+  if (q < (size_t)To * 32) {  // bias in accumulator order [out tile][lane half][16]
+    const int r = (int)(q & 15), hh = (int)((q >> 4) & 1), t = (int)(q >> 5);
+    const int unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    bias[q] = unit < out ? b[unit] : 0.0f;
+  }
+  if (q < (size_t)in * out_pad) {  // float32 transposed copy [in][out_pad]
+    const int o = (int)(q % out_pad), k = (int)(q / out_pad);
+    wt[q] = o < out ? W[(size_t)o * in + k] : 0.0f;
+  }
+  if (q < (size_t)out_pad) bt[q] = q < (size_t)out ? b[q] : 0.0f;
+}
+
 }  // namespace ebc

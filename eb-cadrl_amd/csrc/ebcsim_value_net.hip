@@ -34,6 +34,7 @@ float bf16_to_float(uint16_t b) {
 struct Mlp2 {
   int device = 0, K0 = 0, H = 0, O = 0;
   ebc::PackedLayer L1{}, L2{};
+  ebc::F32Layer F1{}, F2{};  // the same weights transposed in float32 (ebc_mlp2_forward_f32)
   float *final_w = nullptr;  // optional third layer with one output
   float final_b = 0.0f;
   std::vector<void *> allocs;
@@ -77,6 +78,30 @@ int pack_layer(Mlp2 *m, const float *W, const float *b, int out, int in, bool ac
   L->bias = (const float *)db;
   L->in_tiles = Ti;
   L->out_tiles = To;
+  return EBC_OK;
+}
+
+// W [out][in] -> transposed [in][out padded to 64], float32 as it is
+int pack_f32(Mlp2 *m, const float *W, const float *b, int out, int in, ebc::F32Layer *L) {
+  const int out_pad = (out + 63) / 64 * 64;
+  if (out_pad > 64 * EBC_F32_MAXU) return fail(EBC_ERR_UNSUPPORTED, "mlp2: more than 320 units in a layer");
+  std::vector<float> wt((size_t)in * out_pad, 0.0f), bias((size_t)out_pad, 0.0f);
+  for (int o = 0; o < out; ++o) {
+    bias[o] = b[o];
+    for (int k = 0; k < in; ++k) wt[(size_t)k * out_pad + o] = W[(size_t)o * in + k];
+  }
+  void *dw = nullptr, *db = nullptr;
+  HIP_TRY(hipMalloc(&dw, wt.size() * 4));
+  m->allocs.push_back(dw);
+  HIP_TRY(hipMalloc(&db, bias.size() * 4));
+  m->allocs.push_back(db);
+  HIP_TRY(hipMemcpy(dw, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+  L->wt = (const float *)dw;
+  L->b = (const float *)db;
+  L->in = in;
+  L->out = out;
+  L->out_pad = out_pad;
   return EBC_OK;
 }
 
@@ -177,7 +202,7 @@ extern "C" {
 int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
                     const float *b2, const float *w3, const float *b3, void **out) {
   if (!w1 || !b1 || !w2 || !b2 || !out) return fail(EBC_ERR_INVALID, "null argument");
-  if (K0 <= 0 || H <= 0 || O <= 0 || K0 > 224 || O > 224) return fail(EBC_ERR_UNSUPPORTED, "mlp2 dimensions");
+  if (K0 <= 0 || H <= 0 || O <= 0 || K0 > 224 || O > 224 || H > 320) return fail(EBC_ERR_UNSUPPORTED, "mlp2 dimensions");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail(EBC_ERR_DEVICE, "no HIP device: libebcsim has no CPU fallback");
@@ -187,6 +212,8 @@ int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const 
   m->device = device_id; m->K0 = K0; m->H = H; m->O = O;
   int rc = pack_layer(m, w1, b1, H, K0, false, &m->L1);
   if (rc == EBC_OK) rc = pack_layer(m, w2, b2, O, H, true, &m->L2);
+  if (rc == EBC_OK) rc = pack_f32(m, w1, b1, H, K0, &m->F1);
+  if (rc == EBC_OK) rc = pack_f32(m, w2, b2, O, H, &m->F2);
   if (rc == EBC_OK && w3) {
     void *dw = nullptr;
     if (hipMalloc(&dw, (size_t)O * 4) != hipSuccess || hipMemcpy(dw, w3, (size_t)O * 4, hipMemcpyHostToDevice) != hipSuccess)
@@ -214,6 +241,51 @@ int ebc_mlp2_forward(void *mlp, void *stream, const float *x, int M, int relu_ou
   hipStream_t st = (hipStream_t)stream;
   const ebc::MlpExtra ex = {row_bias, group_rows, m->H, m->final_w, m->final_b, nullptr, nullptr, 0, 1};
   return mlp2_dispatch(m, st, x, M, relu_out, y, ex);
+}
+
+int ebc_mlp2_update(void *mlp, void *stream, const float *w1, const float *b1, const float *w2, const float *b2,
+                    const float *w3, const float *b3) {
+  Mlp2 *m = (Mlp2 *)mlp;
+  if (!m || !w1 || !b1 || !w2 || !b2) return fail(EBC_ERR_INVALID, "mlp2 update arguments");
+  if ((m->final_w != nullptr) != (w3 != nullptr)) return fail(EBC_ERR_INVALID, "mlp2 update: third layer given / missing");
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t st = (hipStream_t)stream;
+  struct { const float *W, *b; int out, in, acc; ebc::PackedLayer *L; ebc::F32Layer *F; } layers[2] = {
+      {w1, b1, m->H, m->K0, 0, &m->L1, &m->F1}, {w2, b2, m->O, m->H, 1, &m->L2, &m->F2}};
+  for (auto &l : layers) {
+    const size_t To = (l.out + 31) / 32, Ti = (l.in + 31) / 32;
+    size_t n = To * Ti * 2 * 64 * 8;
+    if ((size_t)l.in * l.F->out_pad > n) n = (size_t)l.in * l.F->out_pad;
+    hipLaunchKernelGGL(ebc::mlp2_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, l.W, l.b, l.out, l.in, l.acc,
+                       (unsigned short *)const_cast<uint4 *>(l.L->frag), const_cast<float *>(l.L->bias),
+                       const_cast<float *>(l.F->wt), const_cast<float *>(l.F->b), l.F->out_pad);
+    HIP_TRY(hipGetLastError());
+  }
+  if (w3) {
+    HIP_TRY(hipMemcpyAsync(m->final_w, w3, (size_t)m->O * 4, hipMemcpyDeviceToDevice, st));
+    float fb = 0.0f;  // the one scalar of the block that lives in the handle: read back (a few bytes, once per update)
+    if (b3) {
+      HIP_TRY(hipMemcpyAsync(&fb, b3, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    m->final_b = fb;
+  }
+  return EBC_OK;
+}
+
+int ebc_mlp2_forward_f32(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
+                         int group_rows, float *y) {
+  Mlp2 *m = (Mlp2 *)mlp;
+  if (!m || !x || !y || M < 0) return fail(EBC_ERR_INVALID, "mlp2 forward arguments");
+  if (row_bias && group_rows <= 0) return fail(EBC_ERR_INVALID, "mlp2: group_rows");
+  if (M == 0) return EBC_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  const size_t lds = (size_t)(m->K0 + m->H) * EBC_F32_ROWS * 4;
+  if (lds > 65536) return fail(EBC_ERR_UNSUPPORTED, "mlp2 float32 block: K0 + H > 1024");
+  hipLaunchKernelGGL(ebc::mlp2_f32_kernel, dim3((unsigned)((M + EBC_F32_ROWS - 1) / EBC_F32_ROWS)), dim3(256), lds, (hipStream_t)stream,
+                     x, M, m->F1, m->F2, relu_out, y, row_bias, group_rows, (const float *)m->final_w, m->final_b);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
 }
 
 int ebc_mlp2_forward_reduce(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,

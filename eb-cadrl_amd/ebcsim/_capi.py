@@ -44,6 +44,10 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "ebc_mlp2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p]),
+    "ebc_mlp2_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+    "ebc_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p]),
     "ebc_mlp2_destroy": (C.c_int, [C.c_void_p]),
     "ebc_mlp2_forward_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                           C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

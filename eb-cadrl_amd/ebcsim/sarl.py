@@ -63,6 +63,34 @@ class _NativeMlp2(object):
                                              y.data_ptr()))
         return y
 
+    def update(self, layers, final=None):
+        """Refresh the packed weights from DEVICE tensors of the shapes the block was created with (ebc_mlp2_update)."""
+        from . import _capi
+        (w1, b1), (w2, b2) = layers
+        t = [x.detach().to(torch.float32).contiguous() for x in (w1, b1, w2, b2)]
+        assert tuple(t[0].shape) == (self.H, self.K0) and tuple(t[2].shape) == (self.O, self.H) and t[0].is_cuda
+        f = None
+        if final is not None:
+            f = [final[0].detach().to(torch.float32).reshape(-1).contiguous(), final[1].detach().to(torch.float32).reshape(-1).contiguous()]
+        _capi.check(self._L.ebc_mlp2_update(self._h, torch.cuda.current_stream(t[0].device).cuda_stream, t[0].data_ptr(),
+                                            t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(),
+                                            None if f is None else f[0].data_ptr(), None if f is None else f[1].data_ptr()))
+
+    def f32(self, x, relu_out, row_bias=None, group_rows=0):
+        """The same block in plain float32 on the vector ALUs (ebc_mlp2_forward_f32): float32-GEMM-grade values for the
+        few rows that decide an argmax."""
+        from . import _capi
+        x = x.contiguous()
+        shape = (x.shape[0],) if self.has_final else (x.shape[0], self.O)
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
+        if row_bias is not None:
+            row_bias = row_bias.contiguous()
+        _capi.check(self._L.ebc_mlp2_forward_f32(self._h, torch.cuda.current_stream(x.device).cuda_stream,
+                                                 x.data_ptr(), int(x.shape[0]), int(bool(relu_out)),
+                                                 None if row_bias is None else row_bias.data_ptr(), int(group_rows),
+                                                 y.data_ptr()))
+        return y
+
     def reduce(self, x, relu_out, seg_rows, row_weight=None, store=True):
         """The block with the row-group sums folded into its epilogue (ebc_mlp2_forward_reduce): -> (y or None,
         partial [ceil(M / 32)][3][O]) — ebc_pair_combine turns the partials into per-pair means / weighted sums."""
@@ -111,42 +139,75 @@ class SarlValueNet(object):
         self.device = torch.device(device)
         self._native = None  # built on first use: (mlp1, mlp2, attention[1:]) as fused two-layer blocks
 
+    def _block_specs(self):
+        """(layers, final) of every libebcsim block of this network, from its CURRENT tensors, or None when the blocks
+        do not apply: [mlp1, mlp2, attention (h1 half of layer 0 + layer 1, layer 2 as the one-output tail),
+        mlp3[:2], mlp3[2:4]] and the mean-state half of attention layer 0 as a block of its own."""
+        ok = (self.device.type == "cuda" and self.dtype == torch.float32 and len(self.mlp1) == 2
+              and len(self.mlp2) == 2 and len(self.attention) == 3 and self.with_global_state)
+        if not ok:
+            return None
+        H = self.mlp1[-1][0].shape[0]
+        # attention = layer 0 on cat([h1, g]) | layer 1 | layer 2 (one output): the h1 half of layer 0
+        # and layer 1 form the block, g's half enters as a per-pair term, layer 2 is the block's tail
+        att = [(self.attention[0][0][:, :H], torch.zeros_like(self.attention[0][1])), self.attention[1]]
+        stacks = (self.mlp1, self.mlp2, att)
+        if not (self.attention[2][0].shape[0] == 1 and all(
+                st[0][0].shape[1] <= 224 and st[1][0].shape[0] <= 224 for st in stacks)):
+            return None
+        specs = [(self.mlp1, None), (self.mlp2, None), (att, self.attention[2])]
+        # mlp3's first two layers (the joint vector's widest ones) as a fourth block; its tail
+        # (the reference's 200 -> 200 -> 1) stays with torch unless it is a two-layer block too
+        if len(self.mlp3) >= 3 and self.mlp3[0][0].shape[1] <= 224 and self.mlp3[1][0].shape[0] <= 224:
+            specs.append((self.mlp3[:2], None))
+            if len(self.mlp3) == 4 and self.mlp3[2][0].shape[1] <= 224 and self.mlp3[3][0].shape[0] <= 224:
+                specs.append((self.mlp3[2:4], None))
+        # the mean state's half of attention layer 0 (one 200 x 200 layer per PAIR) as a block too: the mean of
+        # ReLU outputs is >= 0, so relu(I g) = g and [I | w0[:, H:]] is that layer in the two-layer form
+        gterm = None
+        if self.attention[0][0].shape[0] <= 224:
+            eye = torch.eye(H, dtype=torch.float32, device=self.device)
+            gterm = ([(eye, torch.zeros(H, dtype=torch.float32, device=self.device)),
+                      (self.attention[0][0][:, H:], self.attention[0][1])], None)
+        return specs, gterm
+
     def _native_blocks(self):
-        """The three two-layer stacks of the network as libebcsim blocks (inference on a HIP device,
+        """The two-layer stacks of the network as libebcsim blocks (inference on a HIP device,
         float32 weights, the reference's layer counts); None when that does not apply."""
-        if getattr(self, "_native", ()) is None:  # nets assembled by hand (training) carry no blocks
-            ok = (self.device.type == "cuda" and self.dtype == torch.float32 and len(self.mlp1) == 2
-                  and len(self.mlp2) == 2 and len(self.attention) == 3 and self.with_global_state)
-            H = self.mlp1[-1][0].shape[0] if ok else 0
-            # attention = layer 0 on cat([h1, g]) | layer 1 | layer 2 (one output): the h1 half of layer 0
-            # and layer 1 form the block, g's half enters as a per-pair term, layer 2 is the block's tail
-            att = ok and [(self.attention[0][0][:, :H], torch.zeros_like(self.attention[0][1])), self.attention[1]]
-            stacks = (self.mlp1, self.mlp2, att) if ok else ()
-            if ok and self.attention[2][0].shape[0] == 1 and all(
-                    st[0][0].shape[1] <= 224 and st[1][0].shape[0] <= 224 for st in stacks):
+        if getattr(self, "_native", ()) is None:  # nets assembled by hand for training opt in with enable_native()
+            spec = self._block_specs()
+            if spec is not None:
                 idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
                 # the shapes were checked above: a failure from here on is a HIP error and is raised, never
                 # turned into a silent torch path
-                blocks = [_NativeMlp2(self.mlp1, idx), _NativeMlp2(self.mlp2, idx),
-                          _NativeMlp2(att, idx, final=self.attention[2])]
-                # mlp3's first two layers (the joint vector's widest ones) as a fourth block; its tail
-                # (the reference's 200 -> 200 -> 1) stays with torch
-                if (len(self.mlp3) >= 3 and self.mlp3[0][0].shape[1] <= 224 and self.mlp3[1][0].shape[0] <= 224):
-                    blocks.append(_NativeMlp2(self.mlp3[:2], idx))
-                    # ... and its last two layers (the reference's 200 -> 200 -> 1) as a block with one output
-                    if len(self.mlp3) == 4 and self.mlp3[2][0].shape[1] <= 224 and self.mlp3[3][0].shape[0] <= 224:
-                        blocks.append(_NativeMlp2(self.mlp3[2:4], idx))
-                # the mean state's half of attention layer 0 (one 200 x 200 layer per PAIR) as a block too: the mean of
-                # ReLU outputs is >= 0, so relu(I g) = g and [I | w0[:, H:]] is that layer in the two-layer form
-                eye = torch.eye(H, dtype=torch.float32, device=self.device)
-                self._gterm_block = None
-                if self.attention[0][0].shape[0] <= 224:
-                    self._gterm_block = _NativeMlp2([(eye, torch.zeros(H, dtype=torch.float32, device=self.device)),
-                                                     (self.attention[0][0][:, H:], self.attention[0][1])], idx)
-                self._native = tuple(blocks)
+                specs, gterm = spec
+                self._gterm_block = None if gterm is None else _NativeMlp2(gterm[0], idx)
+                self._native = tuple(_NativeMlp2(layers, idx, final=final) for layers, final in specs)
             else:
                 self._native = ()
         return getattr(self, "_native", ()) or None
+
+    def enable_native(self):
+        """For a network whose tensors are a training module's parameters (SarlModule.as_value_net): build the blocks
+        from the current weights; refresh_native() re-packs them after the weights have changed."""
+        self._native = None
+        return self._native_blocks() is not None
+
+    def refresh_native(self):
+        """Re-pack every block from the network's current tensors, on the device (ebc_mlp2_update: no host copy): the
+        training loop calls this once per round after its optimizer steps (rl/train.py:239-259), so its rollouts decide
+        on the matrix-core blocks like every other decision.  Returns False when the network has no blocks."""
+        nat = getattr(self, "_native", ()) or None
+        if nat is None:
+            return False
+        specs, gterm = self._block_specs()
+        for blk, (layers, final) in zip(nat, specs):
+            blk.update(layers, final)
+        if self._gterm_block is not None:
+            self._gterm_block.update(gterm[0], None)
+        self.native_refreshes = getattr(self, "native_refreshes", 0) + 1
+        self.coarse_eps = None  # other weights: the refinement measures its bound again at the next decision
+        return True
 
     @staticmethod
     def _pair_mean(h1, nv64, B, R):
@@ -211,13 +272,44 @@ class SarlValueNet(object):
         with torch.no_grad():
             return self._forward(rows, n_valid, want_weights, exact)
 
-    def action_values(self, rows, reward, discount, n_valid=None, refine=2, chunk_pairs=None):
+    # |value of the split-bf16 blocks - float32 value| of the NETWORK OUTPUT (before reward and discount) depends on the
+    # weights: <= 3.3e-4 with the shipped eb-cadrl weights on the bench workload (its attention scores are large: a
+    # 2^-16 relative error there is e-4 behind the exponential), <= 1.2e-6 with random-init weights, <= 1.5e-5 on the
+    # reference's golden episodes.  The bound the refinement works with is therefore MEASURED per network
+    # (calibrate_eps: both forms on a sample of the decision batch, times EPS_MARGIN; again after every
+    # refresh_native) and CHECKED at every decision on the candidates that were re-evaluated: one of them off by more
+    # than the bound widens it and the decision is taken again.  COARSE_EPS_MAX: a network whose blocks are worse than
+    # this is refused (the matrix-core path is not fit to rank its values).
+    EPS_MARGIN = 4.0
+    EPS_FLOOR = 2e-6
+    COARSE_EPS_MAX = 5e-3
+    REFINE_CAP = 1 << 30  # no cap by default: every candidate within the bound is re-evaluated (an env near its goal can have dozens)
+
+    def calibrate_eps(self, pairs, n_valid=None, sample=2048):
+        """Measure |matrix-core value - float32 value| on a strided sample of `pairs` [n, R, T] and set the bound the
+        refinement uses (coarse_eps).  One host sync."""
+        n = pairs.shape[0]
+        idx = torch.arange(0, n, max(1, n // int(sample)), device=pairs.device)[:int(sample)]
+        sel = pairs[idx]
+        nv = None if n_valid is None else n_valid[idx]
+        err = float((self.forward(sel, nv) - self.forward(sel, nv, exact=True)).abs().max())
+        if not err <= self.COARSE_EPS_MAX:
+            raise RuntimeError("SarlValueNet: the matrix-core blocks are off by %.2e on this network: not fit to rank its values" % err)
+        self.coarse_eps = max(self.EPS_MARGIN * err, self.EPS_FLOOR)
+        self.measured_coarse_err = err
+        return self.coarse_eps
+
+    def action_values(self, rows, reward, discount, n_valid=None, refine=None, chunk_pairs=None, eps=None):
         """reward + discount * V(rows) for every candidate action (multi_human_rl.py:72-76): rows
         [E, A, R, T] float32, reward [E, A] float64, n_valid [E] or None -> values [E, A] float64.
-        The blocks' values carry <= 1.5e-5 of split-bf16 error, and the reference's own best two actions are
-        sometimes closer than that (5.6e-6 in its golden episodes): the `refine` best candidates of every
-        env are therefore re-evaluated with plain float32 GEMMs (2 of 81 pairs: ~2 % more rows) before the
-        caller takes the argmax, so the DECISION is the float32 network's."""
+        The matrix-core blocks' values carry a split-bf16 error (coarse_eps, measured per network) and the float32
+        network's best two actions can be as close as 4e-7, so the DECISION is made on float32 values: every candidate
+        whose coarse value lies within 2 * discount * eps of the env's coarse best — any action whose float32 value could
+        be the maximum — is re-evaluated with the float32 form of the same blocks (ebc_mlp2_forward_f32) before the
+        caller takes the argmax; the bound is checked on those candidates (a violation widens it and repeats the
+        selection).  refine: None = this bound-driven set; an int k = the best k candidates of every env (0 = the
+        matrix-core values as they are).  refine_stats counts decisions, re-evaluated candidates, envs with more than two
+        of them, the largest set, and bound violations."""
         E, A, R, T = rows.shape
         step = E if not chunk_pairs else max(1, int(chunk_pairs) // A)
         v = torch.empty((E, A), dtype=torch.float32, device=rows.device)
@@ -226,14 +318,45 @@ class SarlValueNet(object):
             nv = None if n_valid is None else n_valid[e0:e1].repeat_interleave(A)
             v[e0:e1] = self.forward(rows[e0:e1].reshape(-1, R, T), nv).view(e1 - e0, A)
         values = reward + discount * v.to(torch.float64)
-        k = min(int(refine), A)
-        if k > 0 and rows.is_cuda and self._native_blocks() is not None:
-            top = torch.topk(values, k, dim=1).indices                       # [E, k]
-            env = torch.arange(E, device=rows.device)[:, None].expand(E, k)
-            sel = rows[env, top].reshape(E * k, R, T)
-            nv = None if n_valid is None else n_valid.repeat_interleave(k)
-            exact = self.forward(sel, nv, exact=True).view(E, k).to(torch.float64)
-            values[env, top] = reward[env, top] + discount * exact
+        if not (rows.is_cuda and self._native_blocks() is not None) or refine == 0:
+            return values
+        if refine is not None:
+            k = min(int(refine), A)
+            top = torch.topk(values, k, dim=1).indices
+            env_i = torch.arange(E, device=rows.device)[:, None].expand(E, k).reshape(-1)
+            act_i = top.reshape(-1)
+            nv = None if n_valid is None else n_valid[env_i]
+            values[env_i, act_i] = reward[env_i, act_i] + discount * self.forward(rows[env_i, act_i], nv, exact=True).to(torch.float64)
+            return values
+        if eps is not None:
+            self.coarse_eps = float(eps)
+        elif getattr(self, "coarse_eps", None) is None:
+            self.calibrate_eps(rows.reshape(E * A, R, T), None if n_valid is None else n_valid.repeat_interleave(A))
+        st = self.__dict__.setdefault("refine_stats", {"decisions": 0, "candidates": 0, "over2": 0, "capped": 0, "max_set": 0,
+                                                       "bound_violations": 0})
+        k = min(self.REFINE_CAP, A)
+        top = torch.topk(values, k, dim=1)                                       # [E, k], best first
+        for attempt in range(4):
+            bound = 2.0 * float(discount) * self.coarse_eps
+            near = top.values >= (top.values[:, :1] - bound)                     # the candidates that could be the float32 best
+            env_i, slot = torch.nonzero(near, as_tuple=True)                     # one host sync per decision batch
+            act_i = top.indices[env_i, slot]
+            nv = None if n_valid is None else n_valid[env_i]
+            exact = self.forward(rows[env_i, act_i], nv, exact=True)
+            worst = float((exact - v[env_i, act_i]).abs().max())                # the bound, checked where it matters
+            if worst <= self.coarse_eps:
+                break
+            st["bound_violations"] += 1
+            if not worst <= self.COARSE_EPS_MAX:
+                raise RuntimeError("SarlValueNet: matrix-core values off by %.2e: not fit to rank this network's values" % worst)
+            self.coarse_eps = self.EPS_MARGIN * worst
+        count = near.sum(1)
+        st["decisions"] += E
+        st["candidates"] += int(env_i.numel())
+        st["over2"] += int((count > 2).sum())
+        st["capped"] += int((count >= k).sum()) if k < A else 0
+        st["max_set"] = max(st["max_set"], int(count.max()))
+        values[env_i, act_i] = reward[env_i, act_i] + discount * exact.to(torch.float64)
         return values
 
     def _forward(self, rows, n_valid=None, want_weights=False, exact=False):
@@ -269,6 +392,25 @@ class SarlValueNet(object):
             if len(nat) > 3:
                 return _mlp(nat[3](joint, True), self.mlp3[2:], False).squeeze(1).to(torch.float32)
             return _mlp(joint, self.mlp3, False).squeeze(1).to(torch.float32)
+        # exact on a HIP device: the float32 form of the same blocks (vector ALUs, fmaf into float32 sums) with the pair
+        # kernels in between — the whole refinement stays inside the library (no hipBLASLt GEMMs, no element-wise launches)
+        natx = None
+        if (exact and rows.is_cuda and not torch.is_grad_enabled() and not want_weights and self.with_global_state
+                and getattr(self, "native_exact", True)):
+            natx = self._native_blocks()
+            if natx is not None and (len(natx) < 5 or self._gterm_block is None or natx[0].O % 4 or natx[1].O % 4
+                                     or natx[1].O > 256):  # what the pair kernels take (else: torch's float32 GEMMs)
+                natx = None
+        if natx is not None:
+            self.native_exact_forwards = getattr(self, "native_exact_forwards", 0) + 1
+            h1 = natx[0].f32(rows.reshape(B * R, T), True)
+            feat = natx[1].f32(h1, False).view(B, R, -1)
+            g = self._pair_mean(h1, nv64, B, R)
+            gterm = self._gterm_block.f32(g, False)
+            scores = natx[2].f32(h1, False, row_bias=gterm, group_rows=R).view(B, R)
+            attended = self._pair_attend(scores, feat, nv64, B, R)
+            joint = torch.cat([self_state, attended], dim=1)
+            return natx[4].f32(natx[3].f32(joint, True), False).squeeze(1)
         if nat is not None:
             self.native_forwards = getattr(self, "native_forwards", 0) + 1  # tests assert the HIP path ran
             h1 = nat[0](rows.reshape(B * R, T), True)
@@ -333,10 +475,11 @@ class SarlValueNet(object):
 class DeviceSarlPolicy(object):
     """Greedy SARL decisions for a whole BatchedEnv (phase "test": no epsilon draw)."""
 
-    def __init__(self, net, actions, gamma, chunk_rows=1 << 21, refine=2):
-        """refine: candidates per env whose value is recomputed in plain float32 before the argmax
-        (SarlValueNet.action_values); 0 = the matrix-core values as they are."""
-        self.refine = int(refine)
+    def __init__(self, net, actions, gamma, chunk_rows=1 << 21, refine=None):
+        """refine: None = every candidate within the matrix-core blocks' error bound of the env's best is recomputed in
+        float32 before the argmax (SarlValueNet.action_values); an int k = the best k; 0 = the matrix-core values as
+        they are."""
+        self.refine = None if refine is None else int(refine)
         self.net = net
         self.actions_np = np.ascontiguousarray(actions, dtype=np.float64)
         self.gamma = float(gamma)

@@ -70,14 +70,20 @@ class SarlModule(torch.nn.Module):
             for k, v in self.named_parameters():
                 v.copy_(sd[self._ref_name(k)])
 
-    def as_value_net(self):
+    def as_value_net(self, native=False):
+        """A SarlValueNet whose tensors ARE this module's parameters (it follows every optimizer step).  native: also
+        build the matrix-core blocks for inference from the current weights — the caller re-packs them with
+        net.refresh_native() after the weights have changed (run_training: once per round)."""
         net = SarlValueNet.__new__(SarlValueNet)
         net.mlp1, net.mlp2 = self._stack("mlp1"), self._stack("mlp2")
         net.attention, net.mlp3 = self._stack("attention"), self._stack("mlp3")
         net.with_global_state, net.self_state_dim = self.with_global_state, self.self_state_dim
         net.input_dim = self._layout["mlp1"][0]
         net.device = next(self.parameters()).device
-        net._native = ()  # the weights change under training: no packed copies of them
+        net.dtype = torch.float32
+        net._native = ()  # the weights change under training: packed copies only on request (native=True)
+        if native and net.device.type == "cuda":
+            net.enable_native()
         return net
 
     def forward(self, rows, n_valid=None):
@@ -494,7 +500,10 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
     import copy
     target = copy.deepcopy(model)                      # explorer.update_target_model (train.py:195)
     trainer.set_learning_rate(rl_learning_rate)
-    policy = DeviceSarlPolicy(model.as_value_net(), actions, gamma)
+    # the rollouts' decisions and the target values run on the matrix-core blocks: packed from the module's weights now,
+    # re-packed on the device (ebc_mlp2_update) after every round's optimizer steps / target refresh
+    policy = DeviceSarlPolicy(model.as_value_net(native=True), actions, gamma)
+    target_net = target.as_value_net(native=True)
     val_policy = DeviceSarlPolicy(policy.net, actions, gamma)  # same network, its own look-ahead buffers (val_env's size)
     t_max = int(round(env.params.time_limit / env.params.time_step)) + 2
     store = EpisodeStore(env.E, t_max, env.R, env.T, dev)
@@ -507,14 +516,16 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
                 log("VAL   in round %d has success rate: %.2f, nav time: %.2f, total reward: %.4f" % (
                     it, m["success_rate"], m["avg_nav_time"], m["total_reward:"]))
         eps = epsilon_start + (epsilon_end - epsilon_start) / epsilon_decay * it if it < epsilon_decay else epsilon_end
-        mean_r = collect(env, policy, target.as_value_net(), memory, steps_per_iteration, gamma, epsilon=eps,
+        mean_r = collect(env, policy, target_net, memory, steps_per_iteration, gamma, epsilon=eps,
                          generator=generator, store=store)
         fresh_pool(steps_per_iteration)
         # ranks fill their shards at different times (an episode reaches the memory when it ends): the
         # optimizer steps all-reduce gradients, so a round trains on every rank or on none
         loss = trainer.optimize_batch(train_batches, generator) if all_ranks(len(memory) > 0, red_dev) else float("nan")
+        policy.net.refresh_native()
         if (it + 1) % target_update_interval == 0:
             target.load_state_dict(model.state_dict())
+            target_net.refresh_native()
         hist["rl_loss"].append(loss)
         hist["mean_reward"].append(mean_r)
         if checkpoint_interval and (it + 1) % checkpoint_interval == 0:
@@ -523,6 +534,9 @@ def run_training(env, model, actions, gamma, il_steps=0, il_epochs=0, il_learnin
             log("iteration %d: epsilon %.3f mean reward %.4f loss %.3e" % (it, eps, mean_r, loss))
     if train_iterations:
         save(os.path.join(output_dir or ".", "rl_model_%d.pth" % train_iterations))
+    # how the rollouts decided: matrix-core forwards and on-device re-packs of the blocks (0 / 0 on a CPU device)
+    hist["native_forwards"] = int(getattr(policy.net, "native_forwards", 0))
+    hist["native_refreshes"] = int(getattr(policy.net, "native_refreshes", 0))
     return hist
 
 

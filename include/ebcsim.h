@@ -411,6 +411,21 @@ int ebc_pair_mean(void *stream, const float *h, const long long *n_valid, int B,
 int ebc_pair_attend(void *stream, const float *scores, const float *feat, const long long *n_valid, int B, int R,
                     int F, float *out);
 
+/* Refresh an existing block from weights in DEVICE memory (torch Linear layout, the shapes it was created with),
+ * enqueued on `stream`: the packed split-bf16 fragments, the biases and the float32 copies are rebuilt by a kernel,
+ * bit-equal to what ebc_mlp2_create packs on the host.  The training loop of rl/train.py:239-259 changes the network
+ * every round; its rollouts are decisions like any others and run on the matrix-core blocks after one such call per
+ * block and round.  w3 / b3: the one-output third layer, for blocks created with one (b3 is read back: one sync). */
+int ebc_mlp2_update(void *mlp, void *stream, const float *w1, const float *b1, const float *w2, const float *b2,
+                    const float *w3, const float *b3);
+
+/* The same block in plain float32 on the vector ALUs (every product an fmaf into a float32 sum, like a float32 GEMM):
+ * for the few rows whose value decides an argmax — SarlValueNet.action_values re-evaluates the candidates that lie
+ * within the split-bf16 error of the best one (rl/policy/multi_human_rl.py:61-80 takes the maximum of float32 values).
+ * Same arguments and outputs as ebc_mlp2_forward. */
+int ebc_mlp2_forward_f32(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
+                         int group_rows, float *y);
+
 /* The same two reductions folded into the block that PRODUCES the activations, so that no second pass reads them
  * (and the features the attention weights multiply are never written at all):
  *   ebc_mlp2_forward_reduce: ebc_mlp2_forward, and per 32-row tile the row-weighted sums of y over each group of

@@ -192,6 +192,14 @@ def test_run_training_imitation_then_rl_on_device():
     assert hist["il_loss"] is not None and np.isfinite(hist["il_loss"])
     assert len(hist["rl_loss"]) == 3 and all(np.isfinite(v) for v in hist["rl_loss"])
     assert len(lines) == 4
+    # the rollouts decided on the matrix-core blocks, re-packed on the device after every round's optimizer steps
+    assert hist["native_refreshes"] == 3 and hist["native_forwards"] >= 3 * 4
+    # ... and those blocks hold the FINAL weights: a fresh host pack of the trained module gives the same values
+    from ebcsim.sarl import SarlValueNet
+    fresh = SarlValueNet({k: v.detach().clone() for k, v in model.state_dict().items()}, device="cuda:0")
+    used = model.as_value_net(native=True)
+    rows = torch.randn(50, env.R, env.T, device="cuda:0")
+    assert torch.equal(fresh.forward(rows), used.forward(rows))
 
 
 @pytest.mark.gpu

@@ -4,6 +4,7 @@ import ctypes as C
 
 import numpy as np
 import pytest
+import torch
 
 
 def _lib():
@@ -193,3 +194,59 @@ def test_mlp2_reduce_refuses_what_it_cannot_do():
     assert L.ebc_mlp2_forward_reduce(h, None, x.data_ptr(), 64, 1, None, 0, None, 8, None, part.data_ptr()) == -2  # EBC_ERR_UNSUPPORTED: groups of 8 rows
     assert L.ebc_mlp2_forward_reduce(h, None, x.data_ptr(), 64, 1, None, 0, None, 16, None, part.data_ptr()) == -2  # a block of 1 + 1 tiles has no tile epilogue
     _capi.check(L.ebc_mlp2_destroy(h))
+
+
+@pytest.mark.gpu
+def test_block_repacked_on_the_device_equals_the_host_pack():
+    """ebc_mlp2_update: a block created from OTHER weights and refreshed from device tensors gives, bit for bit, the
+    outputs of a block created from those weights on the host — the split-bf16 forward, its one-output tail and the
+    float32 form (the fragments, biases and float32 copies are the host packer's)."""
+    from ebcsim.sarl import _NativeMlp2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    for K0, H, O, tail in ((17, 300, 200, False), (200, 200, 100, False), (200, 200, 200, True), (206, 300, 200, False), (200, 200, 1, False)):
+        mk = lambda: [(torch.randn(H, K0, generator=g) / K0 ** 0.5, torch.randn(H, generator=g)),  # noqa: E731
+                      (torch.randn(O, H, generator=g) / H ** 0.5, torch.randn(O, generator=g))]
+        mkf = lambda: (torch.randn(1, O, generator=g), torch.randn(1, generator=g))  # noqa: E731
+        want_l, want_f = mk(), (mkf() if tail else None)
+        a = _NativeMlp2(want_l, 0, final=want_f)
+        b = _NativeMlp2(mk(), 0, final=(mkf() if tail else None))
+        x = torch.randn(1000, K0, generator=g).to(dev)
+        assert not torch.equal(a(x, True), b(x, True))
+        b.update([(w.to(dev), bb.to(dev)) for w, bb in want_l], None if want_f is None else tuple(t.to(dev) for t in want_f))
+        torch.cuda.synchronize()
+        for relu in (True, False):
+            assert torch.equal(a(x, relu), b(x, relu)), (K0, H, O, relu)
+            assert torch.equal(a.f32(x, relu), b.f32(x, relu)), (K0, H, O, relu)
+
+
+@pytest.mark.gpu
+def test_float32_block_is_float32_gemm_grade():
+    """ebc_mlp2_forward_f32 against torch float32 Linear layers (and float64 ones as the yard-stick of both): the
+    refinement's values are as good as a float32 GEMM's, with the per-group term and the one-output tail."""
+    from ebcsim.sarl import _NativeMlp2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(6)
+    for K0, H, O, tail, group in ((17, 300, 200, False, 0), (200, 200, 100, False, 0), (200, 200, 200, True, 18), (206, 300, 200, False, 0),
+                                  (200, 200, 1, False, 0)):
+        w1, b1 = torch.randn(H, K0, generator=g) / K0 ** 0.5, torch.randn(H, generator=g)
+        w2, b2 = torch.randn(O, H, generator=g) / H ** 0.5, torch.randn(O, generator=g)
+        fin = (torch.randn(1, O, generator=g) / O ** 0.5, torch.randn(1, generator=g)) if tail else None
+        blk = _NativeMlp2([(w1, b1), (w2, b2)], 0, final=fin)
+        M = 18 * 53 + 7
+        x = torch.randn(M, K0, generator=g)
+        rb = torch.randn((M + 17) // 18, H, generator=g) if group else None
+
+        def ref(dt):
+            h = torch.nn.functional.linear(x.to(dt), w1.to(dt), b1.to(dt))
+            if rb is not None:
+                h = h + rb.to(dt).repeat_interleave(18, 0)[:M]
+            y = torch.nn.functional.linear(torch.relu(h), w2.to(dt), b2.to(dt))
+            if fin is not None:  # the one-output tail acts on relu(out): the attention stack's third layer (sarl.py:25-27)
+                y = torch.nn.functional.linear(torch.relu(y), fin[0].to(dt), fin[1].to(dt)).squeeze(1)
+            return y
+        got = blk.f32(x.to(dev), False, row_bias=None if rb is None else rb.to(dev), group_rows=18 if group else 0).cpu()
+        exact = ref(torch.float64)
+        err_native = float((got.double() - exact).abs().max())
+        err_torch = float((ref(torch.float32).double() - exact).abs().max())
+        assert err_native <= max(3.0 * err_torch, 2e-6), (K0, H, O, err_native, err_torch)
