@@ -651,142 +651,171 @@ __global__ __launch_bounds__(256) void pair_attend_kernel(const float *scores, c
 // float32 sum, like a float32 GEMM.  For the FEW rows whose value decides an argmax (SarlValueNet.action_values
 // re-evaluates the candidates within the split-bf16 error of the best one): at ~2 % of the rows its speed does not
 // matter, its accuracy does — and the refinement no longer leaves the library for ~11 small hipBLASLt GEMMs and ~20
-// element-wise launches.  16 rows per 256-thread workgroup; lane = output unit (mod 64), wave = 4 of the 16 rows; the
-// input tile and the hidden tile wait transposed in LDS (read as broadcast float4: all lanes of a wave want the same
-// four rows), weights are read transposed [K][units padded to 64] so that a wave's loads are contiguous.
+// element-wise launches.
 struct F32Layer {
   const float *wt;  // [in][out_pad]
   const float *b;   // [out_pad]
   int in, out, out_pad;
 };
-#define EBC_F32_ROWS 16
 #define EBC_F32_MAXU 5  // units of a layer <= 64 * this (the padded width of the transposed weights)
 
-// thread t owns output unit t for all 16 rows of the tile (every weight is loaded by exactly one thread of the
-// workgroup); units 256.. (a 300-wide layer has 44 of them) are shared out as (unit 256 + lane, four rows per wave).
-// Two-level sums (32 products at a time into a partial sum, the partial sums into the total): the rounding error of a
-// 300-term dot product stays at the level of a blocked GEMM's instead of growing with one long chain.
-struct F32Acc {
-  float main[EBC_F32_ROWS];
-  float extra[4];
-};
-__device__ __forceinline__ void f32_layer(const F32Layer &L, const float *inT, int t, F32Acc &acc) {
-  const int lane = t & 63, rg = t >> 6;
-  const bool has_main = t < L.out, has_extra = 256 + lane < L.out;
-#pragma unroll
-  for (int r = 0; r < EBC_F32_ROWS; ++r) acc.main[r] = 0.0f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) acc.extra[q] = 0.0f;
-  for (int k0 = 0; k0 < L.in; k0 += 32) {
-    F32Acc part;
-#pragma unroll
-    for (int r = 0; r < EBC_F32_ROWS; ++r) part.main[r] = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) part.extra[q] = 0.0f;
-    const int k1 = min(k0 + 32, L.in);
-    for (int k = k0; k < k1; ++k) {
-      const float4 *xr = reinterpret_cast<const float4 *>(inT + k * EBC_F32_ROWS);
-      const float *w = L.wt + (size_t)k * L.out_pad;
-      if (has_main) {
-        const float wv = w[t];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 x4 = xr[q];
-          part.main[4 * q] = __builtin_fmaf(x4.x, wv, part.main[4 * q]);
-          part.main[4 * q + 1] = __builtin_fmaf(x4.y, wv, part.main[4 * q + 1]);
-          part.main[4 * q + 2] = __builtin_fmaf(x4.z, wv, part.main[4 * q + 2]);
-          part.main[4 * q + 3] = __builtin_fmaf(x4.w, wv, part.main[4 * q + 3]);
-        }
-      }
-      if (has_extra) {
-        const float wv = w[256 + lane];
-        const float4 x4 = xr[rg];
-        part.extra[0] = __builtin_fmaf(x4.x, wv, part.extra[0]);
-        part.extra[1] = __builtin_fmaf(x4.y, wv, part.extra[1]);
-        part.extra[2] = __builtin_fmaf(x4.z, wv, part.extra[2]);
-        part.extra[3] = __builtin_fmaf(x4.w, wv, part.extra[3]);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < EBC_F32_ROWS; ++r) acc.main[r] += part.main[r];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc.extra[q] += part.extra[q];
-  }
-}
-
-__global__ __launch_bounds__(256) void mlp2_f32_kernel(const float *x, int M, F32Layer L1, F32Layer L2, int relu_out, float *y,
+// A 32-row tile per workgroup, on the float32 matrix instruction (v_mfma_f32_32x32x2_f32: an exact fmaf chain per
+// output, 1/16 of the bf16 rate — plenty for the ~2 % of the rows that are re-evaluated).  Computed transposed like
+// the split-bf16 form: units on the accumulator rows, samples on the lanes, so a finished hidden tile IS the B
+// operand of the next layer as it stands (register r of lane half h holds unit 8 (r >> 2) + 4 h + (r & 3) of the
+// tile: the two units of a k-step are the two lane halves of ONE register, and the second layer's weights are read
+// in that pairing).  A hidden tile is made (K0 / 2 instructions), biased, rectified and consumed at once into the
+// output accumulators; the input tile waits transposed in LDS; weights are read transposed [K][units padded to 64]
+// (a wave's 64 lanes: two contiguous 128-byte runs), one register set ahead of the instructions that use them.
+// A workgroup = four waves = four 32-row tiles that walk the hidden tiles TOGETHER: the weights a hidden tile needs
+// (its 32 columns of W1, its 32 rows of W2: 54 KB at 200 -> 200 -> 200) are staged in LDS once per workgroup by wide
+// coalesced loads and read from there, one ds_read per matrix instruction — with a 4-byte global load per instruction
+// and lane the kernel waited on L2 latency nine tenths of its time (187-287 us per launch instead of ~50).  The wave's
+// input rows come from global memory (L2) as 16-byte loads, sixteen k-steps ahead of their use.
+typedef float f32mfma_acc __attribute__((ext_vector_type(16)));
+template <int T2>  // output tiles (compile time: they index registers)
+__global__ __launch_bounds__(256, 1) void mlp2_f32_kernel(const float *x, int M, F32Layer L1, F32Layer L2, int relu_out, float *y,
                                                        const float *row_bias, int group_rows, const float *final_w,
                                                        float final_b) {
-  extern __shared__ __align__(16) float f32_lds[];
-  float *xT = f32_lds;                                  // [K0][16]
-  float *hT = f32_lds + (size_t)L1.in * EBC_F32_ROWS;   // [H][16]
-  __shared__ float fin_part[4][EBC_F32_ROWS];
-  const int t = threadIdx.x, lane = t & 63, rg = t >> 6;
-  const int row0 = blockIdx.x * EBC_F32_ROWS;
-  const int K0 = L1.in, H = L1.out, O = L2.out;
-  for (int idx = t; idx < EBC_F32_ROWS * K0; idx += 256) {
-    const int r = idx / K0, k = idx - r * K0;
-    xT[k * EBC_F32_ROWS + r] = row0 + r < M ? x[(size_t)(row0 + r) * K0 + k] : 0.0f;
-  }
-  __syncthreads();
-  F32Acc acc;
-  f32_layer(L1, xT, t, acc);
-  auto hidden = [&](int unit, int r, float a) {
-    const int row = row0 + r;
-    float v = a + L1.b[unit];
-    if (row_bias && row < M) v += row_bias[(size_t)(row / group_rows) * H + unit];
-    hT[unit * EBC_F32_ROWS + r] = v > 0.0f ? v : 0.0f;
-  };
-  if (t < H) {
+  extern __shared__ __align__(16) float f32_lds[];  // A1 [K0 rounded up to a multiple of 4][32] | A2 [32][O_pad]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+  const int row = (blockIdx.x * 4 + wave) * 32 + n;
+  const int K0 = L1.in, H = L1.out, O = L2.out, P2 = L2.out_pad;
+  const int K4 = (K0 + 3) & ~3;  // k-steps come in pairs (one 16-byte load of the input row = two of them)
+  float *A1 = f32_lds, *A2 = f32_lds + (size_t)K4 * 32;
+  const float *xr = x + (size_t)(row < M ? row : 0) * K0;
+  const bool x16 = (K0 & 3) == 0;  // rows 16-byte aligned: the wide loads
+  f32mfma_acc out[T2];
 #pragma unroll
-    for (int r = 0; r < EBC_F32_ROWS; ++r) hidden(t, r, acc.main[r]);
-  }
-  if (256 + lane < H) {
+  for (int t = 0; t < T2; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) hidden(256 + lane, 4 * rg + q, acc.extra[q]);
-  }
-  __syncthreads();
-  f32_layer(L2, hT, t, acc);
-  float fin[EBC_F32_ROWS];
+    for (int r = 0; r < 16; ++r) out[t][r] = 0.0f;
+  const int T1 = (H + 31) / 32;
+  const int gq = (row_bias && row < M) ? row / group_rows : 0;
+  // The wave's input rows, ONCE, as the B operands of all its k-steps (this lane's row, the columns of its lane half):
+  // every hidden tile multiplies the same rows, and read per tile from L2 their latency was two thirds of the launch.
+  float xq[112];  // K0 <= 224: 56 column quadruples = 112 k-steps
 #pragma unroll
-  for (int r = 0; r < EBC_F32_ROWS; ++r) fin[r] = 0.0f;
-  auto output = [&](int unit, int r, float a) {
-    const int row = row0 + r;
-    float v = a + L2.b[unit];
-    if (relu_out || final_w) v = v > 0.0f ? v : 0.0f;  // the one-output tail acts on relu(out), like the matrix-core form
-    if (final_w) fin[r] = __builtin_fmaf(final_w[unit], v, fin[r]);
-    else if (row < M) y[(size_t)row * O + unit] = v;
-  };
-  if (t < O) {
-#pragma unroll
-    for (int r = 0; r < EBC_F32_ROWS; ++r) output(t, r, acc.main[r]);
-  }
-  if (256 + lane < O) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      // (fin is indexed by a compile-time row below: add the four rows of this wave's share where they belong)
-      const int unit = 256 + lane, r = 4 * rg + q;
-      float v = acc.extra[q] + L2.b[unit];
-      if (relu_out || final_w) v = v > 0.0f ? v : 0.0f;
-      if (final_w) {
-#pragma unroll
-        for (int rr = 0; rr < EBC_F32_ROWS; ++rr)
-          if (rr == r) fin[rr] = __builtin_fmaf(final_w[unit], v, fin[rr]);
-      } else if (row0 + r < M) {
-        y[(size_t)(row0 + r) * O + unit] = v;
+  for (int j = 0; j < 56; ++j) {
+    const int k = 4 * j;
+    float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (k < K4) {
+      if (x16) {
+        q = *reinterpret_cast<const float4 *>(xr + k);
+      } else {
+        q.x = k < K0 ? xr[k] : 0.0f;
+        q.y = k + 1 < K0 ? xr[k + 1] : 0.0f;
+        q.z = k + 2 < K0 ? xr[k + 2] : 0.0f;
+        q.w = k + 3 < K0 ? xr[k + 3] : 0.0f;
       }
     }
+    xq[2 * j] = half ? q.y : q.x;      // k-step (k, k + 1): lane half h takes column k + h
+    xq[2 * j + 1] = half ? q.w : q.z;  // k-step (k + 2, k + 3)
   }
-  if (final_w) {  // the third layer's one output: units are spread over the 256 threads
+  for (int th = 0; th < T1; ++th) {
+    __syncthreads();  // the previous tile's weights are no longer being read
+    {  // all of a thread's loads go out before its first LDS store (a load-wait-store loop paid one L2 latency per piece:
+       // 14 of them per hidden tile, 11 us of the 15 a tile took)
+      float4 v1[7], v2[8];  // K0 <= 224: at most 7 pieces of W1t[k][32 th .. 32 th + 31] per thread; P2 <= 256: 8 of W2t
+      const int q2 = P2 >> 2;
 #pragma unroll
-    for (int r = 0; r < EBC_F32_ROWS; ++r) {
-      float v = fin[r];
+      for (int j = 0; j < 7; ++j) {
+        const int idx = threadIdx.x + 256 * j, k = idx >> 3, c = (idx & 7) * 4;
+        v1[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (idx < K4 * 8 && k < K0) v1[j] = *reinterpret_cast<const float4 *>(L1.wt + (size_t)k * L1.out_pad + th * 32 + c);
+      }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) fin_part[rg][r] = v;
+      for (int j = 0; j < 8; ++j) {
+        const int idx = threadIdx.x + 256 * j, u = idx / q2, c = (idx - u * q2) * 4;
+        v2[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (idx < 32 * q2 && th * 32 + u < H) v2[j] = *reinterpret_cast<const float4 *>(L2.wt + (size_t)(th * 32 + u) * P2 + c);
+      }
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int idx = threadIdx.x + 256 * j, k = idx >> 3, c = (idx & 7) * 4;
+        if (idx < K4 * 8) *reinterpret_cast<float4 *>(A1 + k * 32 + c) = v1[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = threadIdx.x + 256 * j, u = idx / q2, c = (idx - u * q2) * 4;
+        if (idx < 32 * q2) *reinterpret_cast<float4 *>(A2 + u * P2 + c) = v2[j];
+      }
     }
     __syncthreads();
-    if (t < EBC_F32_ROWS && row0 + t < M) y[row0 + t] = fin_part[0][t] + fin_part[1][t] + fin_part[2][t] + fin_part[3][t] + final_b;
+    // ---- hidden tile th: units 32 th .. 32 th + 31 for the wave's 32 rows
+    f32mfma_acc hid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[r] = 0.0f;
+    // sixteen weights are read from LDS FIRST, then sixteen instructions run back to back (left to the compiler each
+    // instruction waited for its own ds_read: 170 instead of 64 cycles apiece)
+#pragma unroll
+    for (int jb = 0; jb < 7; ++jb) {
+      if (32 * jb < K4) {  // group-uniform
+        float a[16];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 32 * jb + 4 * j < K4 ? 32 * jb + 4 * j : 0;
+          a[2 * j] = A1[(k + half) * 32 + n];
+          a[2 * j + 1] = A1[(k + 2 + half) * 32 + n];
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the scheduler otherwise sinks every read next to its use again
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (32 * jb + 4 * j < K4) {
+            hid = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * j], xq[16 * jb + 2 * j], hid, 0, 0, 0);
+            hid = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * j + 1], xq[16 * jb + 2 * j + 1], hid, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // bias (+ the group's term), ReLU: the tile is now the second layer's B operand, register by register
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int unit = th * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+      float v = hid[r] + (unit < H ? L1.b[unit] : 0.0f);
+      if (row_bias && unit < H && row < M) v += row_bias[(size_t)gq * H + unit];
+      hid[r] = v > 0.0f ? v : 0.0f;
+    }
+    // ---- consumed at once: out[t2] += W2[units of t2][units of th] . hid
+    float wa[T2], wb[T2];  // the weights of step r + 1 are read while step r's instructions run
+    auto read_w2 = [&](int r, float (&w)[T2]) {
+      const float *w2 = A2 + (8 * (r >> 2) + 4 * half + (r & 3)) * P2 + n;
+#pragma unroll
+      for (int t = 0; t < T2; ++t) w[t] = w2[t * 32];
+    };
+    read_w2(0, wa);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      read_w2(r + 1, wb);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < T2; ++t) out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[t], hid[r], out[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r + 2 < 16) read_w2(r + 2, wa);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < T2; ++t) out[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[t], hid[r + 1], out[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- epilogue
+  float fin = 0.0f;
+#pragma unroll
+  for (int t = 0; t < T2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int unit = t * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+      if (unit < O) {
+        float v = out[t][r] + L2.b[unit];
+        if (relu_out || final_w) v = v > 0.0f ? v : 0.0f;  // the one-output tail acts on relu(out), like the matrix-core form
+        if (final_w) fin = __builtin_fmaf(final_w[unit], v, fin);
+        else if (row < M) y[(size_t)row * O + unit] = v;
+      }
+    }
+  if (final_w) {
+    fin += __shfl_xor(fin, 32, 64);
+    if (half == 0 && row < M) y[row] = fin + final_b;
   }
 }
 

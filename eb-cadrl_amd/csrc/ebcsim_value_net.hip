@@ -280,10 +280,32 @@ int ebc_mlp2_forward_f32(void *mlp, void *stream, const float *x, int M, int rel
   if (row_bias && group_rows <= 0) return fail(EBC_ERR_INVALID, "mlp2: group_rows");
   if (M == 0) return EBC_OK;
   HIP_TRY(hipSetDevice(m->device));
-  const size_t lds = (size_t)(m->K0 + m->H) * EBC_F32_ROWS * 4;
-  if (lds > 65536) return fail(EBC_ERR_UNSUPPORTED, "mlp2 float32 block: K0 + H > 1024");
-  hipLaunchKernelGGL(ebc::mlp2_f32_kernel, dim3((unsigned)((M + EBC_F32_ROWS - 1) / EBC_F32_ROWS)), dim3(256), lds, (hipStream_t)stream,
-                     x, M, m->F1, m->F2, relu_out, y, row_bias, group_rows, (const float *)m->final_w, m->final_b);
+  const size_t lds = ((size_t)((m->K0 + 3) & ~3) * 32 + (size_t)32 * m->F2.out_pad) * 4;  // a hidden tile's W1 columns + W2 rows
+  const dim3 grid((unsigned)((M + 127) / 128)), block(256);
+  static size_t raised_dev[64] = {0};  // more than the 64 KB a launch gets by default (per device)
+  if (lds > 65536 && lds > raised_dev[m->device & 63]) {
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    raised_dev[m->device & 63] = lds;
+  }
+  hipStream_t st = (hipStream_t)stream;
+#define F32_(T2) hipLaunchKernelGGL((ebc::mlp2_f32_kernel<T2>), grid, block, lds, st, x, M, m->F1, m->F2, relu_out, y, row_bias, \
+                                    group_rows, (const float *)m->final_w, m->final_b)
+  switch ((m->O + 31) / 32) {
+    case 1: F32_(1); break;
+    case 2: F32_(2); break;
+    case 3: F32_(3); break;
+    case 4: F32_(4); break;
+    case 5: F32_(5); break;
+    case 6: F32_(6); break;
+    default: F32_(7); break;
+  }
+#undef F32_
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }

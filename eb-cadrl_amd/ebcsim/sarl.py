@@ -280,7 +280,7 @@ class SarlValueNet(object):
     # refresh_native) and CHECKED at every decision on the candidates that were re-evaluated: one of them off by more
     # than the bound widens it and the decision is taken again.  COARSE_EPS_MAX: a network whose blocks are worse than
     # this is refused (the matrix-core path is not fit to rank its values).
-    EPS_MARGIN = 4.0
+    EPS_MARGIN = 2.0
     EPS_FLOOR = 2e-6
     COARSE_EPS_MAX = 5e-3
     REFINE_CAP = 1 << 30  # no cap by default: every candidate within the bound is re-evaluated (an env near its goal can have dozens)
@@ -306,7 +306,8 @@ class SarlValueNet(object):
         network's best two actions can be as close as 4e-7, so the DECISION is made on float32 values: every candidate
         whose coarse value lies within 2 * discount * eps of the env's coarse best — any action whose float32 value could
         be the maximum — is re-evaluated with the float32 form of the same blocks (ebc_mlp2_forward_f32) before the
-        caller takes the argmax; the bound is checked on those candidates (a violation widens it and repeats the
+        caller takes the argmax (an env with a single such candidate is decided already and keeps its matrix-core
+        value); the bound is checked on those candidates (a violation widens it and repeats the
         selection).  refine: None = this bound-driven set; an int k = the best k candidates of every env (0 = the
         matrix-core values as they are).  refine_stats counts decisions, re-evaluated candidates, envs with more than two
         of them, the largest set, and bound violations."""
@@ -339,7 +340,12 @@ class SarlValueNet(object):
         for attempt in range(4):
             bound = 2.0 * float(discount) * self.coarse_eps
             near = top.values >= (top.values[:, :1] - bound)                     # the candidates that could be the float32 best
-            env_i, slot = torch.nonzero(near, as_tuple=True)                     # one host sync per decision batch
+            # an env with ONE candidate is decided: every other action's float32 value lies below that one's
+            contested = near & (near.sum(1, keepdim=True) > 1)
+            env_i, slot = torch.nonzero(contested, as_tuple=True)                # one host sync per decision batch
+            if env_i.numel() == 0:
+                exact = None
+                break
             act_i = top.indices[env_i, slot]
             nv = None if n_valid is None else n_valid[env_i]
             exact = self.forward(rows[env_i, act_i], nv, exact=True)
@@ -353,10 +359,12 @@ class SarlValueNet(object):
         count = near.sum(1)
         st["decisions"] += E
         st["candidates"] += int(env_i.numel())
+        st["contested"] = st.get("contested", 0) + int((count > 1).sum())
         st["over2"] += int((count > 2).sum())
         st["capped"] += int((count >= k).sum()) if k < A else 0
         st["max_set"] = max(st["max_set"], int(count.max()))
-        values[env_i, act_i] = reward[env_i, act_i] + discount * exact.to(torch.float64)
+        if exact is not None:
+            values[env_i, act_i] = reward[env_i, act_i] + discount * exact.to(torch.float64)
         return values
 
     def _forward(self, rows, n_valid=None, want_weights=False, exact=False):

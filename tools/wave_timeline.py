@@ -63,7 +63,7 @@ def main():
         if tag == 2:  # orca_step_kernel: blocks in role order ENV, ORCA, ROWS, STATE
             env_blocks = -(-E // (64 // batch.N))
             state_blocks = env_blocks
-            if os.environ.get("EBCSIM_STEP_FORM") == "3":  # the ENV role with a lane per env
+            if os.environ.get("EBCSIM_STEP_FORM", "3") == "3":  # the default form: the ENV role with four lanes per env
                 env_blocks = -(-E // 16)
             others = batch.N - 1 + (1 if params.robot_visible else 0)
             gs = next(g for g in (2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 16, 21, 32) if g >= others)
@@ -121,6 +121,12 @@ def report(np, name, rows, base):
         mk = rows[:, 5:10].astype(np.int64)
         names = ["start->loads ready", "robot action", "distances", "ordered reduce", "grid window", "reward + outputs"]
         segs = [mk[:, 0] - c0] + [mk[:, q + 1] - mk[:, q] for q in range(4)] + [cyc - (mk[:, 4] - c0)]
+        print("   cycles mean: " + ", ".join("%s %.0f" % (n, v.mean()) for n, v in zip(names, segs)))
+    elif name == "ENV" and rows[:, 6].any():  # four lanes per env: marks 1 (action), 2 (quarters combined), 3 (grid), 4 (end)
+        c0 = rows[:, 2].astype(np.int64)
+        mk = rows[:, 6:10].astype(np.int64) - c0[:, None]
+        names = ["start->robot action done", "publish + humans + distances + combine", "grid window", "reward + outputs"]
+        segs = [mk[:, 0]] + [mk[:, q + 1] - mk[:, q] for q in range(3)]
         print("   cycles mean: " + ", ".join("%s %.0f" % (n, v.mean()) for n, v in zip(names, segs)))
     if name == "ORCA":
         last = np.argsort(r1)[-8:]
