@@ -64,6 +64,14 @@ struct MlpExtra {
   const float *row_weight;
   double *partial;
   int seg_rows, store_y;
+  // Round 3: activations handed from block to block ALREADY SPLIT and in fragment order.  frag_out: the output tiles
+  // leave as the B fragments the next block's first layer multiplies — tile_frags() of the finished accumulators,
+  // [row tile][output tile][k-step][hi, lo][lane] 16-byte pieces, the same 4 bytes per element as float32 rows —;
+  // frag_in: the input IS such a tensor (X is not read): no row loads through an LDS transposition tile and no
+  // per-lane split8 in the consumer's input phase.  A consumer of fragments has its first layer packed in accumulator
+  // k order (ebc_mlp2_create_ex, EBC_MLP_IN_FRAGMENTS).
+  const uint4 *frag_in;
+  uint4 *frag_out;
 };
 #define EBC_VN_SEGS 3
 
@@ -183,7 +191,20 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
   }
   // the input tile as B fragments, natural k order: element j of k-step s is k = 16 s + 8 half + j
   Frag2 x[TI][2][1];
-  if (TI >= 2 && (K0 & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)XCAP * 16) {
+  if (ex.frag_in) {
+    // (a workgroup's last waves can lie past the last row tile: the tensor has ceil(M / 32) tiles, they read tile 0)
+    const bool tile_ok = (blockIdx.x * NW + wave) * 32 < M;
+    const uint4 *src = ex.frag_in + (tile_ok ? (size_t)(blockIdx.x * NW + wave) * TI * 4 * PART : 0) + lane;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (KIN != 0 && i == TI - 1 && s2 == 1) continue;
+        const uint4 h = src[((i * 2 + s2) * 2) * PART], l = src[((i * 2 + s2) * 2 + 1) * PART];
+        x[i][s2][0].hi = *reinterpret_cast<const bf16x8 *>(&h);
+        x[i][s2][0].lo = *reinterpret_cast<const bf16x8 *>(&l);
+      }
+  } else if (TI >= 2 && (K0 & 3) == 0 && (size_t)NW * 32 * EBC_VN_XROW <= (size_t)XCAP * 16) {
     // Wide inputs (the 200-float h1 rows of mlp2 / attention) through LDS.  A lane needs ITS row, 8 consecutive
     // floats per k-step: read straight from memory that is 28 16-byte loads per lane at a row stride, every
     // 128-byte line touched by eight different wave instructions with 200+ KB per CU in flight — the lines
@@ -440,8 +461,19 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
       __builtin_amdgcn_wave_barrier();
     }
     const bool store = ex.store_y != 0 || !reduce;
+    // a workgroup's last waves can lie past the last row tile: they own no tile of the outputs that are kept per tile
+    uint4 *fout = (ex.frag_out && m0 < M) ? ex.frag_out + (size_t)(m0 >> 5) * TO * 4 * PART + lane : nullptr;
 #pragma unroll
     for (int t = 0; t < TO; ++t) {
+      if (fout) {  // the tile as the next block's B fragments: 4 x 16 bytes per lane, 1 KB per store instruction
+        Frag2 of[2];
+        tile_frags(out[t][0], relu_out != 0, of);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          fout[((t * 2 + s2) * 2) * PART] = *reinterpret_cast<const uint4 *>(&of[s2].hi);
+          fout[((t * 2 + s2) * 2 + 1) * PART] = *reinterpret_cast<const uint4 *>(&of[s2].lo);
+        }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         vn_f32x4 v;
@@ -472,7 +504,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
         for (int sg = 0; sg < EBC_VN_SEGS; ++sg) {
           double c = (seg_lo == sg ? a0 : 0.0) + (seg_lo + 1 == sg ? a1 : 0.0);
           c += __shfl_xor(c, 32, 64);
-          if (half == 0 && unit < O) ex.partial[((size_t)(m0 >> 5) * EBC_VN_SEGS + sg) * O + unit] = c;
+          if (half == 0 && unit < O && m0 < M) ex.partial[((size_t)(m0 >> 5) * EBC_VN_SEGS + sg) * O + unit] = c;
         }
       }
       __builtin_amdgcn_wave_barrier();

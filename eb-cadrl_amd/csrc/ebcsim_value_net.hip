@@ -35,6 +35,7 @@ struct Mlp2 {
   int device = 0, K0 = 0, H = 0, O = 0;
   ebc::PackedLayer L1{}, L2{};
   ebc::F32Layer F1{}, F2{};  // the same weights transposed in float32 (ebc_mlp2_forward_f32)
+  int in_frag = 0;           // EBC_MLP_IN_FRAGMENTS: the first layer packed in accumulator k order (input = fragments)
   float *final_w = nullptr;  // optional third layer with one output
   float final_b = 0.0f;
   std::vector<void *> allocs;
@@ -201,6 +202,11 @@ extern "C" {
 
 int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
                     const float *b2, const float *w3, const float *b3, void **out) {
+  return ebc_mlp2_create_ex(device_id, K0, H, O, w1, b1, w2, b2, w3, b3, 0, out);
+}
+
+int ebc_mlp2_create_ex(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
+                       const float *b2, const float *w3, const float *b3, int flags, void **out) {
   if (!w1 || !b1 || !w2 || !b2 || !out) return fail(EBC_ERR_INVALID, "null argument");
   if (K0 <= 0 || H <= 0 || O <= 0 || K0 > 224 || O > 224 || H > 320) return fail(EBC_ERR_UNSUPPORTED, "mlp2 dimensions");
   int count = 0;
@@ -210,7 +216,8 @@ int ebc_mlp2_create(int device_id, int K0, int H, int O, const float *w1, const 
   HIP_TRY(hipSetDevice(device_id));
   Mlp2 *m = new Mlp2();
   m->device = device_id; m->K0 = K0; m->H = H; m->O = O;
-  int rc = pack_layer(m, w1, b1, H, K0, false, &m->L1);
+  m->in_frag = (flags & EBC_MLP_IN_FRAGMENTS) ? 1 : 0;
+  int rc = pack_layer(m, w1, b1, H, K0, m->in_frag != 0, &m->L1);
   if (rc == EBC_OK) rc = pack_layer(m, w2, b2, O, H, true, &m->L2);
   if (rc == EBC_OK) rc = pack_f32(m, w1, b1, H, K0, &m->F1);
   if (rc == EBC_OK) rc = pack_f32(m, w2, b2, O, H, &m->F2);
@@ -251,7 +258,7 @@ int ebc_mlp2_update(void *mlp, void *stream, const float *w1, const float *b1, c
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t st = (hipStream_t)stream;
   struct { const float *W, *b; int out, in, acc; ebc::PackedLayer *L; ebc::F32Layer *F; } layers[2] = {
-      {w1, b1, m->H, m->K0, 0, &m->L1, &m->F1}, {w2, b2, m->O, m->H, 1, &m->L2, &m->F2}};
+      {w1, b1, m->H, m->K0, m->in_frag, &m->L1, &m->F1}, {w2, b2, m->O, m->H, 1, &m->L2, &m->F2}};
   for (auto &l : layers) {
     const size_t To = (l.out + 31) / 32, Ti = (l.in + 31) / 32;
     size_t n = To * Ti * 2 * 64 * 8;
@@ -322,6 +329,32 @@ int ebc_mlp2_forward_reduce(void *mlp, void *stream, const float *x, int M, int 
   HIP_TRY(hipSetDevice(m->device));
   const ebc::MlpExtra ex = {row_bias, group_rows, m->H, nullptr, 0.0f, row_weight, partial, seg_rows, y ? 1 : 0};
   return mlp2_dispatch(m, (hipStream_t)stream, x, M, relu_out, y, ex);
+}
+
+int ebc_mlp2_forward_ex(void *mlp, void *stream, const EbcMlpArgs *a) {
+  Mlp2 *m = (Mlp2 *)mlp;
+  if (!m || !a || a->struct_size != sizeof(EbcMlpArgs)) return fail(EBC_ERR_INVALID, "EbcMlpArgs.struct_size");
+  if (a->M < 0 || (!a->x && !a->frag_in)) return fail(EBC_ERR_INVALID, "mlp2 forward_ex: no input");
+  if ((a->frag_in != nullptr) != (m->in_frag != 0))
+    return fail(EBC_ERR_INVALID, "mlp2 forward_ex: fragment input needs a block created with EBC_MLP_IN_FRAGMENTS, row input one without");
+  if (a->row_bias && a->group_rows <= 0) return fail(EBC_ERR_INVALID, "mlp2: group_rows");
+  if (a->partial) {
+    if (m->final_w) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_ex: a block with a one-output third layer has no [M][O] rows");
+    if (a->seg_rows < 16) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_ex: groups of fewer than 16 rows");
+  }
+  if ((a->partial || a->frag_out) && (m->O & 3)) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_ex: O must be a multiple of 4");
+  if (a->frag_out && m->final_w) return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_ex: a one-output block has no tiles to hand on");
+  if (!a->y && !a->partial && !a->frag_out) return fail(EBC_ERR_INVALID, "mlp2 forward_ex: no output");
+  if (a->M == 0) return EBC_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  // the tile epilogue writes rows only when asked to (store_y) once partial sums or fragments are wanted
+  const int store_y = a->y ? 1 : 0;
+  ebc::MlpExtra ex = {a->row_bias, a->group_rows, m->H, m->final_w, m->final_b, a->row_weight, a->partial, a->seg_rows, store_y,
+                      (const uint4 *)a->frag_in, (uint4 *)a->frag_out};
+  if (!a->partial && a->frag_out) {  // fragments without sums: the sums' machinery with nothing to add up to
+    return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_ex: frag_out comes with partial sums (the tile epilogue)");
+  }
+  return mlp2_dispatch(m, (hipStream_t)stream, a->x, a->M, a->relu_out, a->y, ex);
 }
 
 int ebc_pair_weights(void *stream, const float *scores, const long long *n_valid, int B, int R, float *w) {

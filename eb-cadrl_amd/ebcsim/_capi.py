@@ -44,6 +44,9 @@ SYMBOLS = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "ebc_mlp2_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p]),
+    "ebc_mlp2_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "ebc_mlp2_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ebc_mlp2_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "ebc_mlp2_forward_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,

@@ -31,8 +31,9 @@ def _mlp(x, layers, last_relu):
 class _NativeMlp2(object):
     """A two-layer block on the bf16 matrix cores with split operands (libebcsim ebc_mlp2_*)."""
 
-    def __init__(self, layers, device_index, final=None):
-        """layers: [(w1, b1), (w2, b2)]; final: optional (w3 [1, O], b3 [1]) third layer with one output."""
+    def __init__(self, layers, device_index, final=None, in_fragments=False):
+        """layers: [(w1, b1), (w2, b2)]; final: optional (w3 [1, O], b3 [1]) third layer with one output.
+        in_fragments: the block's input is the fragment tensor another block left with `frag_out` (ebc_mlp2_forward_ex)."""
         import ctypes as C
         from . import _capi
         (w1, b1), (w2, b2) = layers
@@ -44,11 +45,47 @@ class _NativeMlp2(object):
             host += [final[0].detach().to("cpu", torch.float32).reshape(-1).contiguous().numpy(),
                      final[1].detach().to("cpu", torch.float32).reshape(-1).contiguous().numpy()]
         self._h = C.c_void_p()
-        _capi.check(self._L.ebc_mlp2_create(int(device_index), self.K0, self.H, self.O, host[0].ctypes.data,
-                                            host[1].ctypes.data, host[2].ctypes.data, host[3].ctypes.data,
-                                            host[4].ctypes.data if final is not None else None,
-                                            host[5].ctypes.data if final is not None else None,
-                                            C.byref(self._h)))
+        self.in_fragments = bool(in_fragments)
+        _capi.check(self._L.ebc_mlp2_create_ex(int(device_index), self.K0, self.H, self.O, host[0].ctypes.data,
+                                               host[1].ctypes.data, host[2].ctypes.data, host[3].ctypes.data,
+                                               host[4].ctypes.data if final is not None else None,
+                                               host[5].ctypes.data if final is not None else None,
+                                               _abi.MLP_IN_FRAGMENTS if in_fragments else 0, C.byref(self._h)))
+
+    @staticmethod
+    def frag_buffer(M, width, device):
+        """Storage for an [M, width] activation handed on in fragment order: [row tiles][column tiles][2][2][64] x 16 B."""
+        return torch.empty(((M + 31) // 32, (width + 31) // 32, 2, 2, 64, 4), dtype=torch.int32, device=device)
+
+    def forward_ex(self, M, relu_out, x=None, frag_in=None, row_bias=None, group_rows=0, want_y=True, seg_rows=0,
+                   row_weight=None, want_partial=False, frag_out=None):
+        """Every form of the forward in one call (ebc_mlp2_forward_ex): rows or fragments in; rows, per-group partial
+        sums and / or fragments out.  -> (y or None, partial or None)."""
+        from . import _capi
+        dev = (x if x is not None else frag_in).device
+        a = _abi.EbcMlpArgs()
+        a.struct_size = self._C.sizeof(a)
+        a.M, a.relu_out, a.group_rows, a.seg_rows = int(M), int(bool(relu_out)), int(group_rows), int(seg_rows)
+        keep = []
+        if x is not None:
+            x = x.contiguous(); keep.append(x); a.x = x.data_ptr()
+        if frag_in is not None:
+            a.frag_in = frag_in.data_ptr()
+        if row_bias is not None:
+            row_bias = row_bias.contiguous(); keep.append(row_bias); a.row_bias = row_bias.data_ptr()
+        if row_weight is not None:
+            row_weight = row_weight.contiguous(); keep.append(row_weight); a.row_weight = row_weight.data_ptr()
+        y = partial = None
+        if want_y:
+            y = torch.empty((M,) if self.has_final else (M, self.O), dtype=torch.float32, device=dev)
+            a.y = y.data_ptr()
+        if want_partial:
+            partial = torch.empty(((M + 31) // 32, 3, self.O), dtype=torch.float64, device=dev)
+            a.partial = partial.data_ptr()
+        if frag_out is not None:
+            a.frag_out = frag_out.data_ptr()
+        _capi.check(self._L.ebc_mlp2_forward_ex(self._h, torch.cuda.current_stream(dev).cuda_stream, self._C.addressof(a)))
+        return y, partial
 
     def __call__(self, x, relu_out, row_bias=None, group_rows=0):
         from . import _capi
@@ -183,6 +220,9 @@ class SarlValueNet(object):
                 specs, gterm = spec
                 self._gterm_block = None if gterm is None else _NativeMlp2(gterm[0], idx)
                 self._native = tuple(_NativeMlp2(layers, idx, final=final) for layers, final in specs)
+                # the two consumers of h1 once more, taking it as the fragments mlp1 leaves (no transposition, no splitting
+                # in their input phase): mlp2 and the attention stack
+                self._native_frag = tuple(_NativeMlp2(layers, idx, final=final, in_fragments=True) for layers, final in specs[1:3])
             else:
                 self._native = ()
         return getattr(self, "_native", ()) or None
@@ -202,6 +242,8 @@ class SarlValueNet(object):
             return False
         specs, gterm = self._block_specs()
         for blk, (layers, final) in zip(nat, specs):
+            blk.update(layers, final)
+        for blk, (layers, final) in zip(getattr(self, "_native_frag", ()), specs[1:3]):
             blk.update(layers, final)
         if self._gterm_block is not None:
             self._gterm_block.update(gterm[0], None)
@@ -383,16 +425,30 @@ class SarlValueNet(object):
             self.native_forwards = getattr(self, "native_forwards", 0) + 1
             self.folded_forwards = getattr(self, "folded_forwards", 0) + 1
             mask = None if nv64 is None else self._pair_mask(nv64, B, R)
-            h1, part = nat[0].reduce(rows.reshape(B * R, T), True, R, mask)
+            natf = getattr(self, "_native_frag", ()) if getattr(self, "frag_handoff", True) else ()
+            H1 = nat[0].O
+            if len(natf) == 2:
+                # h1 never exists as float32 rows: mlp1 leaves it split and in fragment order, its consumers load that
+                M = B * R
+                h1f = _NativeMlp2.frag_buffer(M, H1, rows.device)
+                _, part = nat[0].forward_ex(M, True, x=rows.reshape(M, T), want_y=False, seg_rows=R, row_weight=mask,
+                                            want_partial=True, frag_out=h1f)
+            else:
+                h1, part = nat[0].reduce(rows.reshape(B * R, T), True, R, mask)
             g = self._pair_combine(part, nv64, B, R, True)
             if self._gterm_block is not None:
                 gterm = self._gterm_block(g, False)
             else:
                 w0, b0 = self.attention[0]
-                gterm = torch.nn.functional.linear(g, w0[:, h1.shape[1]:], b0)
-            scores = nat[2](h1, False, row_bias=gterm, group_rows=R)
-            w = self._pair_weights(scores, nv64, B, R)
-            _, part = nat[1].reduce(h1, False, R, w, store=False)
+                gterm = torch.nn.functional.linear(g, w0[:, H1:], b0)
+            if len(natf) == 2:
+                scores, _ = natf[1].forward_ex(M, False, frag_in=h1f, row_bias=gterm, group_rows=R)
+                w = self._pair_weights(scores, nv64, B, R)
+                _, part = natf[0].forward_ex(M, False, frag_in=h1f, want_y=False, seg_rows=R, row_weight=w, want_partial=True)
+            else:
+                scores = nat[2](h1, False, row_bias=gterm, group_rows=R)
+                w = self._pair_weights(scores, nv64, B, R)
+                _, part = nat[1].reduce(h1, False, R, w, store=False)
             attended = self._pair_combine(part, None, B, R, False)
             joint = torch.cat([self_state, attended], dim=1)
             if len(nat) > 4:

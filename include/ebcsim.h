@@ -411,6 +411,29 @@ int ebc_pair_mean(void *stream, const float *h, const long long *n_valid, int B,
 int ebc_pair_attend(void *stream, const float *scores, const float *feat, const long long *n_valid, int B, int R,
                     int F, float *out);
 
+/* Activations handed from block to block already split and in fragment order (round 3).  A block created with
+ * EBC_MLP_IN_FRAGMENTS takes its input as the tensor another block wrote with `frag_out`: per 32-row tile and 32-column
+ * tile, the two k-steps' hi / lo bf16 fragments as the matrix cores take them (16 bytes per lane and piece; the same 4
+ * bytes per element as float32 rows, rows and columns padded to 32) — the consumer's input phase is 16-byte loads,
+ * no transposition through LDS and no per-lane splitting.  Both sides tile the rows from row 0 in steps of 32.
+ * ebc_mlp2_forward_ex: every form of the forward in one call: x (rows) or frag_in; y (rows, may be NULL), partial /
+ * seg_rows / row_weight as in ebc_mlp2_forward_reduce, frag_out [ceil(M / 32)][ceil(O / 32)][2][2][64] x 16 bytes. */
+#define EBC_MLP_IN_FRAGMENTS 1
+typedef struct EbcMlpArgs {
+  uint32_t struct_size;
+  int32_t M, relu_out, group_rows, seg_rows;
+  const float *x;
+  const void *frag_in;
+  const float *row_bias;
+  const float *row_weight;
+  float *y;
+  double *partial;
+  void *frag_out;
+} EbcMlpArgs;
+int ebc_mlp2_create_ex(int device_id, int K0, int H, int O, const float *w1, const float *b1, const float *w2,
+                       const float *b2, const float *w3, const float *b3, int flags, void **mlp_out);
+int ebc_mlp2_forward_ex(void *mlp, void *stream, const EbcMlpArgs *args);
+
 /* Refresh an existing block from weights in DEVICE memory (torch Linear layout, the shapes it was created with),
  * enqueued on `stream`: the packed split-bf16 fragments, the biases and the float32 copies are rebuilt by a kernel,
  * bit-equal to what ebc_mlp2_create packs on the host.  The training loop of rl/train.py:239-259 changes the network

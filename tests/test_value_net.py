@@ -250,3 +250,32 @@ def test_float32_block_is_float32_gemm_grade():
         err_native = float((got.double() - exact).abs().max())
         err_torch = float((ref(torch.float32).double() - exact).abs().max())
         assert err_native <= max(3.0 * err_torch, 2e-6), (K0, H, O, err_native, err_torch)
+
+
+@pytest.mark.gpu
+def test_fragment_handoff_equals_row_handoff():
+    """h1 handed from mlp1 to the attention stack and to mlp2 as split fragments (ebc_mlp2_forward_ex: frag_out ->
+    frag_in) against the same network with h1 as float32 rows: the same float32 values split the same way, multiplied
+    in another k order — values agree to float32 rounding, ragged pairs included."""
+    import os
+    from ebcsim.sarl import SarlValueNet
+    from helpers import GOLDEN
+    dev = torch.device("cuda", 0)
+    net = SarlValueNet.load(os.path.join(GOLDEN, "weights", "sarl_n10_ebcadrl.pth"), device=str(dev))
+    g = torch.Generator().manual_seed(9)
+    B, R, T = 777, 18, 17
+    rows = torch.randn(B, R, T, generator=g).to(dev)
+    rows[:, :, 13:] = 0
+    rows[:, :, 13] = 1
+    nv = torch.randint(16, R + 1, (B,), generator=g).to(dev)
+    for n_valid in (None, nv):
+        net.frag_handoff = True
+        a = net.forward(rows, n_valid)
+        assert net._native_frag and net.folded_forwards > 0
+        net.frag_handoff = False
+        b = net.forward(rows, n_valid)
+        ref = net.forward(rows, n_valid, exact=True)
+        torch.cuda.synchronize()
+        ea, eb = float((a - ref).abs().max()), float((b - ref).abs().max())
+        assert ea <= max(2.0 * eb, 2e-5 * max(1.0, float(ref.abs().max()))), (ea, eb)
+        print("fragment hand-off error %.3g, row hand-off error %.3g" % (ea, eb))
