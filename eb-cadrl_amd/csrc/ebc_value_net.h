@@ -690,6 +690,7 @@ struct F32Layer {
   int in, out, out_pad;
 };
 #define EBC_F32_MAXU 5  // units of a layer <= 64 * this (the padded width of the transposed weights)
+#define EBC_F32_TILE_ROWS (1 << 16)  // up to this many rows ebc_mlp2_forward_f32 takes the workgroup-per-tile form
 
 // A 32-row tile per workgroup, on the float32 matrix instruction (v_mfma_f32_32x32x2_f32: an exact fmaf chain per
 // output, 1/16 of the bf16 rate — plenty for the ~2 % of the rows that are re-evaluated).  Computed transposed like
@@ -848,6 +849,180 @@ __global__ __launch_bounds__(256, 1) void mlp2_f32_kernel(const float *x, int M,
   if (final_w) {
     fin += __shfl_xor(fin, 32, 64);
     if (half == 0 && row < M) y[row] = fin + final_b;
+  }
+}
+
+// The same block when the rows are FEW (a decision re-evaluates ~1000 rows = ~34 tiles): above, a wave walks all
+// hidden and output tiles of its 32 rows alone — ~1500 dependent 64-cycle instructions and 14 staging round trips,
+// 144 us for a launch that fills 9 of 256 CUs.  Here a workgroup is ONE 32-row tile and its waves share the tile's
+// work: wave w makes hidden tiles w, w + NW, ... (all of K0 each), parks them in LDS in the accumulator layout (again
+// the next layer's B operand as it stands), and after one barrier makes output tiles w, w + NW, ... from all of them.
+// The input tile is loaded once per workgroup, transposed into LDS; weights come straight from L2 in the transposed
+// layout (a wave's lanes: two contiguous 128-byte runs per instruction), sixteen instructions' worth per batch, two
+// batches ahead of the instructions that use them.  Same products and float32 sums per output, k ascending.
+template <int I>
+struct IntC {
+  static constexpr int value = I;
+};
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void mlp2_f32_tile_kernel(const float *x, int M, F32Layer L1, F32Layer L2, int relu_out, float *y,
+                                                                const float *row_bias, int group_rows, const float *final_w,
+                                                                float final_b) {
+  extern __shared__ __align__(16) float f32t_lds[];  // x [K4][32] | hidden [T1][4][64] float4 | fin [NW][32]
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (uniform, and known to be: scalar branches and offsets)
+  const int lane = threadIdx.x & 63, n = lane & 31, half = lane >> 5;
+  const int m0 = blockIdx.x * 32, row = m0 + n;
+  const int K0 = L1.in, H = L1.out, O = L2.out, P1 = L1.out_pad, P2 = L2.out_pad;
+  const int K4 = (K0 + 3) & ~3, T1 = (H + 31) / 32, T2 = (O + 31) / 32;
+  float *xl = f32t_lds;
+  float4 *hl = reinterpret_cast<float4 *>(f32t_lds + (size_t)K4 * 32);
+  float *finl = f32t_lds + (size_t)K4 * 32 + (size_t)T1 * 1024;
+  // weights through buffer descriptors: one 32-bit lane offset per tile, the k-step in the scalar offset, and the
+  // range check instead of clamps (with 64-bit addresses per load the compiler kept 112 of them live and spilled)
+  const auto r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L1.wt), 0, K0 * P1 * 4, 0x00020000);
+  const auto r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L2.wt), 0, H * P2 * 4, 0x00020000);
+  // ---- the input tile, once: thread -> (column quadruple c, row r), transposed into xl[k][r] (lanes = rows: no conflict)
+  {
+    const bool x16 = (K0 & 3) == 0;
+    for (int idx = threadIdx.x; idx < K4 * 8; idx += NW * 64) {
+      const int c = idx >> 5, r = idx & 31, k = 4 * c;
+      const float *xr = x + (size_t)(m0 + r < M ? m0 + r : 0) * K0;
+      float4 q;
+      if (x16) {
+        q = *reinterpret_cast<const float4 *>(xr + k);
+      } else {
+        q.x = k < K0 ? xr[k] : 0.0f;
+        q.y = k + 1 < K0 ? xr[k + 1] : 0.0f;
+        q.z = k + 2 < K0 ? xr[k + 2] : 0.0f;
+        q.w = k + 3 < K0 ? xr[k + 3] : 0.0f;
+      }
+      xl[(k + 0) * 32 + r] = q.x;
+      xl[(k + 1) * 32 + r] = q.y;
+      xl[(k + 2) * 32 + r] = q.z;
+      xl[(k + 3) * 32 + r] = q.w;
+    }
+  }
+  __syncthreads();
+  const int gq = (row_bias && row < M) ? row / group_rows : 0;
+  // ---- layer 1: hidden tiles wave, wave + NW, ...
+  for (int u = wave; u < T1; u += NW) {
+    const int voff = (half * P1 + u * 32 + n) * 4;  // the lane's part of the address; the k-step's is wave-uniform
+    float a[3][16];
+    auto load_a = [&](int jb, float (&w)[16]) {  // batch jb: k-steps (32 jb + 4 j, + 2), this lane half's column of each
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // (rows >= K0 lie past the descriptor's range and read as 0)
+        w[2 * j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, voff, (32 * jb + 4 * j) * P1 * 4, 0));
+        w[2 * j + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, voff, (32 * jb + 4 * j + 2) * P1 * 4, 0));
+      }
+    };
+    // No branch inside a batch and no way into one but through the batch before it (the break): the loads two batches
+    // ahead are then unconditionally in flight where the compiler counts them, and it waits for exactly the batch it
+    // uses.  (Loads and k-steps past K0 cost a batch's tail at most: the descriptor returns 0 for them.)
+    load_a(0, a[0]);
+    load_a(1, a[1]);
+    f32mfma_acc hid;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hid[r] = 0.0f;
+    auto batch = [&](auto ic) -> bool {
+      constexpr int jb = decltype(ic)::value;
+      if (32 * jb >= K4) return false;  // uniform
+      if (jb + 2 < 7) load_a(jb + 2, a[(jb + 2) % 3]);
+      float b[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 32 * jb + 4 * j < K4 ? 32 * jb + 4 * j : 0;  // (a row of the tile: finite, times weight 0)
+        b[2 * j] = xl[(k + half) * 32 + n];
+        b[2 * j + 1] = xl[(k + 2 + half) * 32 + n];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        hid = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jb % 3][2 * j], b[2 * j], hid, 0, 0, 0);
+        hid = __builtin_amdgcn_mfma_f32_32x32x2f32(a[jb % 3][2 * j + 1], b[2 * j + 1], hid, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      return true;
+    };
+    (void)(batch(IntC<0>{}) && batch(IntC<1>{}) && batch(IntC<2>{}) && batch(IntC<3>{}) && batch(IntC<4>{}) && batch(IntC<5>{}) &&
+           batch(IntC<6>{}));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int unit = u * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+      float v = hid[r] + (unit < H ? L1.b[unit] : 0.0f);
+      if (row_bias && unit < H && row < M) v += row_bias[(size_t)gq * H + unit];
+      hid[r] = v > 0.0f ? v : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hl[(u * 4 + q) * 64 + lane] = make_float4(hid[4 * q], hid[4 * q + 1], hid[4 * q + 2], hid[4 * q + 3]);
+  }
+  __syncthreads();
+  // ---- layer 2: output tiles wave, wave + NW, ... from every hidden tile
+  float fin = 0.0f;
+  for (int t = wave; t < T2; t += NW) {
+    const int voff = (4 * half * P2 + t * 32 + n) * 4;
+    float a[3][16];
+    auto load_a = [&](int u, float (&w)[16]) {  // hidden tile u: step r pairs units 8 (r >> 2) + (r & 3) and + 4 (the lane halves)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        w[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r2, voff, (u * 32 + 8 * (r >> 2) + (r & 3)) * P2 * 4, 0));
+    };
+    load_a(0, a[0]);
+    load_a(1, a[1]);
+    f32mfma_acc out;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = 0.0f;
+    auto batch = [&](auto ic) -> bool {
+      constexpr int u = decltype(ic)::value;
+      if (u >= T1) return false;  // uniform
+      if (u + 2 < 10) load_a(u + 2, a[(u + 2) % 3]);
+      float b[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = hl[(u * 4 + q) * 64 + lane];
+        b[4 * q] = v.x;
+        b[4 * q + 1] = v.y;
+        b[4 * q + 2] = v.z;
+        b[4 * q + 3] = v.w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u % 3][r], b[r], out, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      return true;
+    };
+    (void)(batch(IntC<0>{}) && batch(IntC<1>{}) && batch(IntC<2>{}) && batch(IntC<3>{}) && batch(IntC<4>{}) && batch(IntC<5>{}) &&
+           batch(IntC<6>{}) && batch(IntC<7>{}) && batch(IntC<8>{}) && batch(IntC<9>{}));
+    const bool wide = (O & 3) == 0 && !final_w;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int unit0 = t * 32 + 8 * q + 4 * half;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int unit = unit0 + i;
+        v[i] = out[4 * q + i] + (unit < O ? L2.b[unit] : 0.0f);
+        if (relu_out || final_w) v[i] = v[i] > 0.0f ? v[i] : 0.0f;  // the one-output tail acts on relu(out)
+        if (final_w && unit < O) fin = __builtin_fmaf(final_w[unit], v[i], fin);
+      }
+      if (final_w || row >= M) continue;
+      if (wide) {
+        if (unit0 < O) *reinterpret_cast<float4 *>(y + (size_t)row * O + unit0) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (unit0 + i < O) y[(size_t)row * O + unit0 + i] = v[i];
+      }
+    }
+  }
+  if (final_w) {  // uniform: the waves' shares of the dot product, added in wave order
+    fin += __shfl_xor(fin, 32, 64);
+    if (half == 0) finl[wave * 32 + n] = fin;
+    __syncthreads();
+    if (wave == 0 && half == 0 && row < M) {
+      float s = 0.0f;
+      for (int w = 0; w < NW && w < T2; ++w) s += finl[w * 32 + n];
+      y[row] = s + final_b;
+    }
   }
 }
 

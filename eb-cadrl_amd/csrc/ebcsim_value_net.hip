@@ -287,6 +287,24 @@ int ebc_mlp2_forward_f32(void *mlp, void *stream, const float *x, int M, int rel
   if (row_bias && group_rows <= 0) return fail(EBC_ERR_INVALID, "mlp2: group_rows");
   if (M == 0) return EBC_OK;
   HIP_TRY(hipSetDevice(m->device));
+  hipStream_t st = (hipStream_t)stream;
+  // few rows: a workgroup per 32-row tile, its waves sharing the tile (the form a decision's re-evaluation gets); many
+  // rows: four tiles per workgroup walking the hidden tiles together on weights staged in LDS.  EBCSIM_F32_FORM=1/2
+  // forces the many-/few-row form (measurements).
+  static const int form = [] { const char *e = getenv("EBCSIM_F32_FORM"); return e ? atoi(e) : 0; }();
+  if (form == 2 || (form == 0 && M <= EBC_F32_TILE_ROWS)) {
+    constexpr int NW = 8;
+    const size_t tl = ((size_t)((m->K0 + 3) & ~3) * 32 + (size_t)((m->H + 31) / 32) * 1024 + NW * 32) * 4;
+    static size_t raised_tile[64] = {0};
+    if (tl > 65536 && tl > raised_tile[m->device & 63]) {
+      HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_tile_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
+      raised_tile[m->device & 63] = tl;
+    }
+    hipLaunchKernelGGL((ebc::mlp2_f32_tile_kernel<NW>), dim3((unsigned)((M + 31) / 32)), dim3(NW * 64), tl, st, x, M, m->F1, m->F2,
+                       relu_out, y, row_bias, group_rows, (const float *)m->final_w, m->final_b);
+    HIP_TRY(hipGetLastError());
+    return EBC_OK;
+  }
   const size_t lds = ((size_t)((m->K0 + 3) & ~3) * 32 + (size_t)32 * m->F2.out_pad) * 4;  // a hidden tile's W1 columns + W2 rows
   const dim3 grid((unsigned)((M + 127) / 128)), block(256);
   static size_t raised_dev[64] = {0};  // more than the 64 KB a launch gets by default (per device)
@@ -300,7 +318,6 @@ int ebc_mlp2_forward_f32(void *mlp, void *stream, const float *x, int M, int rel
     HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_f32_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised_dev[m->device & 63] = lds;
   }
-  hipStream_t st = (hipStream_t)stream;
 #define F32_(T2) hipLaunchKernelGGL((ebc::mlp2_f32_kernel<T2>), grid, block, lds, st, x, M, m->F1, m->F2, relu_out, y, row_bias, \
                                     group_rows, (const float *)m->final_w, m->final_b)
   switch ((m->O + 31) / 32) {

@@ -233,7 +233,12 @@ def test_float32_block_is_float32_gemm_grade():
         w2, b2 = torch.randn(O, H, generator=g) / H ** 0.5, torch.randn(O, generator=g)
         fin = (torch.randn(1, O, generator=g) / O ** 0.5, torch.randn(1, generator=g)) if tail else None
         blk = _NativeMlp2([(w1, b1), (w2, b2)], 0, final=fin)
-        M = 18 * 53 + 7
+        for M in (18 * 53 + 7, (1 << 16) + 18 * 2 + 5) if K0 == 200 else (18 * 53 + 7,):  # few rows: a workgroup per tile; many: four tiles
+            _check_f32_block(blk, M, K0, H, O, w1, b1, w2, b2, fin, group, g, dev)
+
+
+def _check_f32_block(blk, M, K0, H, O, w1, b1, w2, b2, fin, group, g, dev):
+    if True:
         x = torch.randn(M, K0, generator=g)
         rb = torch.randn((M + 17) // 18, H, generator=g) if group else None
 
