@@ -1,0 +1,243 @@
+// ebc_vn_stream.h — the attention block of the SARL value network (/root/reference/rl/policy/sarl.py:61-72:
+// attention = mlp(cat([h1, g]), [.., .., 1])) for the widest shapes, streamed.
+//
+// The general block (mlp2_split_wg_kernel, ebc_value_net.h) keeps a wave's INPUT fragments in registers across all
+// hidden tiles.  At 7 input + 7 output tiles that is 104 + 112 registers before anything else: the compiler spilled 21
+// of them, and every reload inside the loop is an `s_waitcnt vmcnt(0)` that also waits for the weight staging in
+// flight behind it (one in-order counter) — the matrix pipe sat at 26 % busy (profiles/r03_value_net_pmc.txt).
+//
+// Here the loops are turned inside out so that nothing wide stays resident:
+//   phase A, one PERIOD per input tile i: hacc[u] += W1[u][i] . x[i] for ALL hidden tiles u (TH accumulators; the
+//     input fragments of one tile are loaded, used for 3 TH instructions and dropped);
+//   phase B: bias (in the accumulators from the start) + the pair's group term, ReLU, split: the TH hidden tiles
+//     become the 2 TH fragments of the second layer, in place;
+//   phase C, one period per output tile t: out = W2[t][.] . hid over all hidden tiles, then the one-output third
+//     layer's share of that tile at once (out is one accumulator, not TO of them).
+// Every period multiplies one 28 KB SLAB of weights (TH fragments x 2 k-steps x hi/lo), the same for all waves of the
+// workgroup: slabs arrive by LDS-DMA two periods ahead into a ring of three; input fragments come from the hand-off
+// tensor (MlpExtra.frag_in: already split, already in fragment order) by plain 16-byte loads hidden in asm, two
+// periods ahead into a ring of three register sets.  ONE barrier per period, in front of it ONE counted wait that
+// leaves the newest period's loads in flight.  Products and sums per output are those of the general block, in the
+// same order: the two kernels agree bit for bit (tests/test_value_net.py).
+#pragma once
+
+#include "ebc_vn_common.h"
+
+namespace ebc {
+
+template <int... I>
+struct IntSeq {};
+template <int N, int... I>
+struct MakeIntSeq : MakeIntSeq<N - 1, N - 1, I...> {};
+template <int... I>
+struct MakeIntSeq<0, I...> {
+  using type = IntSeq<I...>;
+};
+template <class F, int... I>
+__device__ __forceinline__ void for_each_int(F &&f, IntSeq<I...>) {
+  (f(IntC<I>{}), ...);
+}
+
+typedef unsigned vn_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {  // at most N vector-memory operations of this wave still in flight
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// TI / TH / TO: input / hidden / output tiles; KIN / KH: the input (hidden) width ends in the first half of its last
+// tile: that tile's second k-step multiplies zeros and is left out.
+template <int TI, int TH, int TO, int NW, int KIN, int KH>
+__global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLayer L1, PackedLayer L2, float *Y, int O, MlpExtra ex) {
+  extern __shared__ uint4 sbuf[];  // slab ring [3][TH][2][2][64] | hidden bias | output bias | third layer | group terms
+  constexpr int PART = 64, SLAB = TH * 4 * PART, PIECES = TH * 4;
+  constexpr int NST = (PIECES + NW - 1) / NW;  // staging instructions per wave and slab (the last waves repeat the last piece)
+  constexpr int P = TI + TO;                   // periods
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, col = lane & 31, half = lane >> 5;
+  const int tile = blockIdx.x * NW + wave, m0w = tile * 32, m = m0w + col;
+  float *hbias = reinterpret_cast<float *>(sbuf + 3 * SLAB), *obias = hbias + TH * 32, *fwl = obias + TO * 32;
+  const LdsF4 gt = (LdsF4)(reinterpret_cast<unsigned char *>(fwl + TO * 32) + (size_t)wave * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH);
+
+  auto stage = [&](int p) {  // slab p -> ring slot p % 3
+    uint4 *dst = sbuf + (p % 3) * SLAB;
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      int q = wave + NW * j;
+      if (q > PIECES - 1) q = PIECES - 1;
+      // phase A slab i: pieces (u, s, hi/lo) of L1 [u][i][s][hi/lo]; phase C slab t: L2 [t][u][s][hi/lo], contiguous
+      const uint4 *src = p < TI ? L1.frag + ((size_t)(q >> 2) * TI + p) * 4 * PART + (size_t)(q & 3) * PART
+                                : L2.frag + (size_t)(p - TI) * SLAB + (size_t)q * PART;
+      unsigned keep;
+      const uint4 *gsrc = src + lane;
+      const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(dst + (size_t)q * PART));
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    }
+  };
+  // the wave's input fragments: [row tile][input tile][k-step][hi, lo][lane] (a tile past M reads tile 0: the tensor has
+  // ceil(M / 32) tiles)
+  const uint4 *xsrc = ex.frag_in + (m0w < M ? (size_t)tile * TI * 4 * PART : 0) + lane;
+  vn_u32x4 xr[3][4];  // (a register vector type: asm operands)
+  auto xload = [&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    const uint4 *src = xsrc + (size_t)p * 4 * PART;
+    vn_u32x4 &r0 = xr[p % 3][0], &r1 = xr[p % 3][1], &r2 = xr[p % 3][2], &r3 = xr[p % 3][3];
+    if (KIN && p == TI - 1)
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:1024" : "=&v"(r0), "=&v"(r1) : "v"(src) : "memory");
+    else
+      asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:1024\n\t"
+                   "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:3072"
+                   : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(src) : "memory");
+  };
+
+  // ---- what the loop must not load from memory (an ordinary load's wait would also wait for the staging): the biases,
+  // the third layer in accumulator order, the group terms of the wave's rows -> LDS
+  for (int q = threadIdx.x; q < TH * 32; q += 64 * NW) hbias[q] = L1.bias[q];
+  for (int q = threadIdx.x; q < TO * 32; q += 64 * NW) {
+    obias[q] = L2.bias[q];
+    const int t = q >> 5, hh = (q >> 4) & 1, r = q & 15, unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    fwl[q] = unit < O ? ex.final_w[unit] : 0.0f;
+  }
+  const int Hp = (ex.H + 3) & ~3;  // floats per parked row
+  {
+    const int first = m0w / ex.group_rows;
+    const int groups_total = (M + ex.group_rows - 1) / ex.group_rows;
+    for (int q = lane; q < EBC_VN_GROUPS * (Hp / 4); q += 64) {
+      const int gq = q / (Hp / 4), c4 = q - gq * (Hp / 4);
+      vn_f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (first + gq < groups_total) v = *reinterpret_cast<const vn_f32x4 *>(ex.row_bias + (size_t)(first + gq) * ex.H + 4 * c4);
+      gt[(gq * EBC_VN_GROUP_PITCH) / 16 + c4] = v;
+    }
+  }
+  const int g_local = m < M ? m / ex.group_rows - m0w / ex.group_rows : -1;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- prologue: the loads of periods 0 and 1
+  xload(IntC<0>{});
+  stage(0);
+  if constexpr (TI > 1) xload(IntC<1>{});
+  stage(1);
+
+  f32x16 hacc[TH];
+  // ---- phase A
+  auto period_a = [&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    // the loads of period p have landed when at most those of period p + 1 are in flight (issue order = period order)
+    constexpr int later = NST + (p + 1 < TI ? ((KIN && p + 1 == TI - 1) ? 2 : 4) : 0);
+    {
+      vn_u32x4 &r0 = xr[p % 3][0], &r1 = xr[p % 3][1], &r2 = xr[p % 3][2], &r3 = xr[p % 3][3];
+      if (KIN && p == TI - 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(later) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(later) : "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's share of slab p is in; every wave is done reading slab p - 1
+    asm volatile("" ::: "memory");
+    if constexpr (p + 2 < TI) xload(IntC<p + 2>{});
+    if constexpr (p + 2 < P) stage(p + 2);
+    if constexpr (p == 0) {
+#pragma unroll
+      for (int u = 0; u < TH; ++u) {
+        const float4 *hb = reinterpret_cast<const float4 *>(hbias + (u * 2 + half) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = hb[q];
+          hacc[u][4 * q] = v.x; hacc[u][4 * q + 1] = v.y; hacc[u][4 * q + 2] = v.z; hacc[u][4 * q + 3] = v.w;
+        }
+      }
+    }
+    // the slab's fragments are read TWO steps (a step = one fragment pair, three instructions) ahead of their use, in
+    // program order pinned by the scheduling barriers: left alone the compiler reads a pair, waits, multiplies, and the
+    // LDS latency of every pair lies open
+    const uint4 *w = sbuf + (p % 3) * SLAB + lane;
+    constexpr int STEPS = (KIN && p == TI - 1) ? TH : 2 * TH;  // step k: k-step s = k / TH of hidden tile u = k % TH
+    uint4 fh[3], fl[3];
+    auto fread = [&](int k) {
+      const int s = k / TH, u = k % TH;
+      fh[k % 3] = w[((u * 2 + s) * 2) * PART];
+      fl[k % 3] = w[((u * 2 + s) * 2 + 1) * PART];
+    };
+    fread(0);
+    fread(1);
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+      if (k + 2 < STEPS) fread(k + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      const int s = k / TH, u = k % TH;
+      const bf16x8 xh = *reinterpret_cast<const bf16x8 *>(&xr[p % 3][2 * s]), xl = *reinterpret_cast<const bf16x8 *>(&xr[p % 3][2 * s + 1]);
+      const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(&fh[k % 3]), wl = *reinterpret_cast<const bf16x8 *>(&fl[k % 3]);
+      hacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, hacc[u], 0, 0, 0);
+      hacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, hacc[u], 0, 0, 0);
+      hacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, hacc[u], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for_each_int(period_a, typename MakeIntSeq<TI>::type{});
+
+  // ---- phase B: + the group term of this lane's row, ReLU, split
+  Frag2 hf[TH][2];
+#pragma unroll
+  for (int u = 0; u < TH; ++u) {
+    f32x16 hid = hacc[u];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int unit = u * 32 + 8 * g + 4 * half;
+      if (g_local >= 0 && unit + 3 < Hp) {
+        const vn_f32x4 t = gt[(g_local * EBC_VN_GROUP_PITCH) / 16 + unit / 4];
+        hid[4 * g] += t.x; hid[4 * g + 1] += t.y; hid[4 * g + 2] += t.z; hid[4 * g + 3] += t.w;
+      }
+    }
+    tile_frags(hid, true, hf[u]);
+  }
+
+  // ---- phase C
+  float acc = 0.0f;
+  for (int t = 0; t < TO; ++t) {
+    const int p = TI + t;
+    if (t + 1 < TO) vm_wait<NST>();
+    else vm_wait<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < TO) stage(p + 2);
+    f32x16 out;
+    {
+      const float4 *ob = reinterpret_cast<const float4 *>(obias + (t * 2 + half) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = ob[q];
+        out[4 * q] = v.x; out[4 * q + 1] = v.y; out[4 * q + 2] = v.z; out[4 * q + 3] = v.w;
+      }
+    }
+    const uint4 *w = sbuf + (p % 3) * SLAB + lane;
+    constexpr int STEPS = KH ? 2 * TH - 1 : 2 * TH;  // step k: k-step s = k % 2 of hidden tile u = k / 2 (the general block's order)
+    uint4 fh[3], fl[3];
+    auto fread = [&](int k) {
+      const int s = k & 1, u = k >> 1;
+      fh[k % 3] = w[((u * 2 + s) * 2) * PART];
+      fl[k % 3] = w[((u * 2 + s) * 2 + 1) * PART];
+    };
+    fread(0);
+    fread(1);
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) {
+      if (k + 2 < STEPS) fread(k + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      const int s = k & 1, u = k >> 1;
+      const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(&fh[k % 3]), wl = *reinterpret_cast<const bf16x8 *>(&fl[k % 3]);
+      out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, hf[u][s].hi, out, 0, 0, 0);
+      out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, hf[u][s].lo, out, 0, 0, 0);
+      out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, hf[u][s].hi, out, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the third layer's share of this tile: units in register order, like the general block
+    const float *fw = fwl + (t * 2 + half) * 16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (unit < O) acc += fw[r] * fmaxf(out[r], 0.0f);
+    }
+  }
+  acc += __shfl_xor(acc, 32, 64);
+  if (m < M && half == 0) Y[m] = acc + ex.final_b;
+}
+
+}  // namespace ebc

@@ -11,6 +11,7 @@
 
 #include "ebc_host.h"
 #include "ebc_value_net.h"
+#include "ebc_vn_stream_api.h"
 
 using ebc_host::fail;
 
@@ -370,6 +371,10 @@ int ebc_mlp2_forward_ex(void *mlp, void *stream, const EbcMlpArgs *a) {
                       (const uint4 *)a->frag_in, (uint4 *)a->frag_out};
   if (!a->partial && a->frag_out) {  // fragments without sums: the sums' machinery with nothing to add up to
     return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_ex: frag_out comes with partial sums (the tile epilogue)");
+  }
+  if (!(a->flags & EBC_MLP_GENERAL_KERNEL)) {  // the attention block at its widest: the streamed kernel (ebc_vn_stream.h)
+    const int rc = ebc_host::vn_stream_launch(m->device, (hipStream_t)stream, a->M, m->L1, m->L2, m->K0, m->H, m->O, a->y, ex);
+    if (rc != EBC_VN_STREAM_NA) return rc;
   }
   return mlp2_dispatch(m, (hipStream_t)stream, a->x, a->M, a->relu_out, a->y, ex);
 }

@@ -129,11 +129,12 @@ class EbcStateView(C.Structure):
 
 
 MLP_IN_FRAGMENTS = 1
+MLP_GENERAL_KERNEL = 1
 
 
 class EbcMlpArgs(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("M", C.c_int32), ("relu_out", C.c_int32), ("group_rows", C.c_int32),
-                ("seg_rows", C.c_int32)] + [(k, C.c_void_p) for k in ("x", "frag_in", "row_bias", "row_weight", "y", "partial",
+                ("seg_rows", C.c_int32), ("flags", C.c_int32)] + [(k, C.c_void_p) for k in ("x", "frag_in", "row_bias", "row_weight", "y", "partial",
                                                                        "frag_out")]
 
 

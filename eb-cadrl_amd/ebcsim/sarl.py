@@ -58,7 +58,7 @@ class _NativeMlp2(object):
         return torch.empty(((M + 31) // 32, (width + 31) // 32, 2, 2, 64, 4), dtype=torch.int32, device=device)
 
     def forward_ex(self, M, relu_out, x=None, frag_in=None, row_bias=None, group_rows=0, want_y=True, seg_rows=0,
-                   row_weight=None, want_partial=False, frag_out=None):
+                   row_weight=None, want_partial=False, frag_out=None, general=False):
         """Every form of the forward in one call (ebc_mlp2_forward_ex): rows or fragments in; rows, per-group partial
         sums and / or fragments out.  -> (y or None, partial or None)."""
         from . import _capi
@@ -66,6 +66,7 @@ class _NativeMlp2(object):
         a = _abi.EbcMlpArgs()
         a.struct_size = self._C.sizeof(a)
         a.M, a.relu_out, a.group_rows, a.seg_rows = int(M), int(bool(relu_out)), int(group_rows), int(seg_rows)
+        a.flags = _abi.MLP_GENERAL_KERNEL if general else 0  # the general block where a specialised kernel exists
         keep = []
         if x is not None:
             x = x.contiguous(); keep.append(x); a.x = x.data_ptr()
@@ -442,7 +443,8 @@ class SarlValueNet(object):
                 w0, b0 = self.attention[0]
                 gterm = torch.nn.functional.linear(g, w0[:, H1:], b0)
             if len(natf) == 2:
-                scores, _ = natf[1].forward_ex(M, False, frag_in=h1f, row_bias=gterm, group_rows=R)
+                scores, _ = natf[1].forward_ex(M, False, frag_in=h1f, row_bias=gterm, group_rows=R,
+                                               general=getattr(self, "general_kernels", False))
                 w = self._pair_weights(scores, nv64, B, R)
                 _, part = natf[0].forward_ex(M, False, frag_in=h1f, want_y=False, seg_rows=R, row_weight=w, want_partial=True)
             else:

@@ -419,9 +419,13 @@ int ebc_pair_attend(void *stream, const float *scores, const float *feat, const 
  * ebc_mlp2_forward_ex: every form of the forward in one call: x (rows) or frag_in; y (rows, may be NULL), partial /
  * seg_rows / row_weight as in ebc_mlp2_forward_reduce, frag_out [ceil(M / 32)][ceil(O / 32)][2][2][64] x 16 bytes. */
 #define EBC_MLP_IN_FRAGMENTS 1
+#define EBC_MLP_GENERAL_KERNEL 1
 typedef struct EbcMlpArgs {
   uint32_t struct_size;
   int32_t M, relu_out, group_rows, seg_rows;
+  int32_t flags; /* EBC_MLP_GENERAL_KERNEL: the general block even where a specialised kernel exists (the streamed
+                    attention block of ebc_vn_stream.h takes fragment input + row_bias + a one-output third layer at
+                    7 x 7 x 7 tiles): same values bit for bit — for measurements and for the test that says so */
   const float *x;
   const void *frag_in;
   const float *row_bias;

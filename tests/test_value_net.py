@@ -284,3 +284,31 @@ def test_fragment_handoff_equals_row_handoff():
         ea, eb = float((a - ref).abs().max()), float((b - ref).abs().max())
         assert ea <= max(2.0 * eb, 2e-5 * max(1.0, float(ref.abs().max()))), (ea, eb)
         print("fragment hand-off error %.3g, row hand-off error %.3g" % (ea, eb))
+
+
+@pytest.mark.gpu
+def test_streamed_attention_block_equals_the_general_block_bit_for_bit():
+    """The attention block at 7 x 7 x 7 tiles runs as the streamed kernel (ebc_vn_stream.h: periods over input tiles, then
+    over output tiles; nothing wide resident).  Same products, same sums, same order as the general block
+    (EBC_MLP_GENERAL_KERNEL): the scores must be the same BITS — whole pairs, ragged pairs, a last tile that is not
+    full, a workgroup whose last waves lie past the rows."""
+    from ebcsim.sarl import _NativeMlp2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    for K0, H, O in ((200, 200, 200), (224, 200, 200), (200, 224, 196), (220, 212, 224)):
+        w1, b1 = torch.randn(H, K0, generator=g) / K0 ** 0.5, torch.randn(H, generator=g)
+        w2, b2 = torch.randn(O, H, generator=g) / H ** 0.5, torch.randn(O, generator=g)
+        fin = (torch.randn(1, O, generator=g) / O ** 0.5, torch.randn(1, generator=g))
+        src = _NativeMlp2([(torch.randn(64, 17, generator=g), torch.randn(64, generator=g)),
+                           (torch.randn(K0, 64, generator=g) / 8, torch.randn(K0, generator=g))], 0)
+        blk = _NativeMlp2([(w1, b1), (w2, b2)], 0, final=fin, in_fragments=True)
+        for M in (18 * 600, 18 * 57 + 5, 31, 32 * 8 * 3 + 1):
+            x = torch.randn(M, 17, generator=g).to(dev)
+            frag = _NativeMlp2.frag_buffer(M, K0, dev)
+            src.forward_ex(M, True, x=x, want_y=False, seg_rows=18, want_partial=True, frag_out=frag)
+            rb = torch.randn((M + 17) // 18, H, generator=g).to(dev)
+            a, _ = blk.forward_ex(M, False, frag_in=frag, row_bias=rb, group_rows=18)
+            b, _ = blk.forward_ex(M, False, frag_in=frag, row_bias=rb, group_rows=18, general=True)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b), (K0, H, O, M, float((a - b).abs().max()))
+            assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0
