@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
       if (TIGHT) {  // one k-step's fragment at a time: eight registers fewer live across the output MFMAs
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaxf(hid[8 * s + j], 0.0f);
+        for (int j = 0; j < 8; ++j) v[j] = relu_bits(hid[8 * s + j]);
         hf[s] = split8(v);
       }
 #pragma unroll
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (unit < O) acc += ex.final_w[unit] * fmaxf(out[t][0][r], 0.0f);
+        if (unit < O) acc += ex.final_w[unit] * relu_bits(out[t][0][r]);
       }
     acc += __shfl_xor(acc, 32, 64);
     if (m < M && half == 0) Y[m] = acc + ex.final_b;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
       for (int g = 0; g < 4; ++g) {
         vn_f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = relu_out ? fmaxf(out[t][0][4 * g + c], 0.0f) : out[t][0][4 * g + c];
+        for (int c = 0; c < 4; ++c) v[c] = relu_out ? relu_bits(out[t][0][4 * g + c]) : out[t][0][4 * g + c];
         yt[(col * EBC_VN_XROW + (8 * g + 4 * half) * 4) / 16] = v;  // units 8 g + 4 half .. + 3 of row `col`
       }
       __builtin_amdgcn_wave_barrier();
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
         const int unit = t * 32 + 8 * g + 4 * half;
         float v[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = relu_out ? fmaxf(out[t][0][4 * g + c], 0.0f) : out[t][0][4 * g + c];
+        for (int c = 0; c < 4; ++c) v[c] = relu_out ? relu_bits(out[t][0][4 * g + c]) : out[t][0][4 * g + c];
         float *dst = Y + (size_t)m * O + unit;
         if (vec && unit + 3 < O) {
           *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);

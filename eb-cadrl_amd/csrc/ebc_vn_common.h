@@ -80,13 +80,21 @@ __device__ __forceinline__ f32x16 bias_tile(const PackedLayer &L, int t, int lan
   return acc;
 }
 
+// max(v, 0) for a finite v as ONE integer instruction on the bits (a negative float is a negative integer; -0 -> +0):
+// fmaxf costs two, the first a canonicalisation of its operand that IEEE mode demands for signalling NaNs.  (A NaN with
+// the sign bit clear stays a NaN where fmaxf gives 0: the blocks' values are finite or the result is garbage anyway.)
+__device__ __forceinline__ float relu_bits(float v) {
+  const int b = __float_as_int(v);
+  return __int_as_float(b > 0 ? b : 0);
+}
+
 // the two B fragments (k-steps) a finished 32x32 tile offers to the next layer
 __device__ __forceinline__ void tile_frags(const f32x16 &acc, bool relu, Frag2 (&out)[2]) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = relu ? fmaxf(acc[8 * s + j], 0.0f) : acc[8 * s + j];
+    for (int j = 0; j < 8; ++j) v[j] = relu ? relu_bits(acc[8 * s + j]) : acc[8 * s + j];
     out[s] = split8(v);
   }
 }

@@ -57,6 +57,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
   const int tile = blockIdx.x * NW + wave, m0w = tile * 32, m = m0w + col;
   float *hbias = reinterpret_cast<float *>(sbuf + 3 * SLAB), *obias = hbias + TH * 32, *fwl = obias + TO * 32;
   const LdsF4 gt = (LdsF4)(reinterpret_cast<unsigned char *>(fwl + TO * 32) + (size_t)wave * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH);
+#ifdef EBC_VNS_TRACE  // measurement build (tools/vn_stream_timeline.py): per wave and period, the clock before the
+                      // counted wait, after it, after the barrier
+  unsigned long long *trl = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(fwl + TO * 32) +
+                                                                   (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH) + (size_t)wave * P * 4;
+  auto stamp = [&](int p, int k) {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (lane == 0) trl[p * 4 + k] = t;
+  };
+#else
+  auto stamp = [](int, int) {};
+#endif
 
   auto stage = [&](int p) {  // slab p -> ring slot p % 3
     uint4 *dst = sbuf + (p % 3) * SLAB;
@@ -123,14 +134,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
     constexpr int p = decltype(ic)::value;
     // the loads of period p have landed when at most those of period p + 1 are in flight (issue order = period order)
     constexpr int later = NST + (p + 1 < TI ? ((KIN && p + 1 == TI - 1) ? 2 : 4) : 0);
+    stamp(p, 0);
     {
       vn_u32x4 &r0 = xr[p % 3][0], &r1 = xr[p % 3][1], &r2 = xr[p % 3][2], &r3 = xr[p % 3][3];
       if (KIN && p == TI - 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r0), "+v"(r1) : "n"(later) : "memory");
       else asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "n"(later) : "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(p, 1);
     __builtin_amdgcn_s_barrier();  // every wave's share of slab p is in; every wave is done reading slab p - 1
     asm volatile("" ::: "memory");
+    stamp(p, 2);
     if constexpr (p + 2 < TI) xload(IntC<p + 2>{});
     if constexpr (p + 2 < P) stage(p + 2);
     if constexpr (p == 0) {
@@ -180,10 +194,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int unit = u * 32 + 8 * g + 4 * half;
-      if (g_local >= 0 && unit + 3 < Hp) {
-        const vn_f32x4 t = gt[(g_local * EBC_VN_GROUP_PITCH) / 16 + unit / 4];
-        hid[4 * g] += t.x; hid[4 * g + 1] += t.y; hid[4 * g + 2] += t.z; hid[4 * g + 3] += t.w;
-      }
+      const bool on = g_local >= 0 && unit + 3 < Hp;  // (read always, from a parked row; selected afterwards: no branch per piece)
+      const vn_f32x4 t = gt[((on ? g_local : 0) * EBC_VN_GROUP_PITCH) / 16 + (unit + 3 < Hp ? unit / 4 : 0)];
+      hid[4 * g] += on ? t.x : 0.0f; hid[4 * g + 1] += on ? t.y : 0.0f; hid[4 * g + 2] += on ? t.z : 0.0f; hid[4 * g + 3] += on ? t.w : 0.0f;
     }
     tile_frags(hid, true, hf[u]);
   }
@@ -192,11 +205,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
   float acc = 0.0f;
   for (int t = 0; t < TO; ++t) {
     const int p = TI + t;
+    stamp(p, 0);
     if (t + 1 < TO) vm_wait<NST>();
     else vm_wait<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    stamp(p, 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    stamp(p, 2);
     if (t + 2 < TO) stage(p + 2);
     f32x16 out;
     {
@@ -228,16 +244,30 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
       out = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, hf[u][s].hi, out, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the third layer's share of this tile: units in register order, like the general block
-    const float *fw = fwl + (t * 2 + half) * 16;
+    // the third layer's share of this tile: units in register order, like the general block.  Its weights are read as
+    // four 16-byte pieces and every product is added — the padding units' weights are parked as 0 and their outputs
+    // are finite, so they add +0 — : a test per unit was a branch and a 4-byte LDS read apiece, 16 latencies in a row.
+    const float4 *fw = reinterpret_cast<const float4 *>(fwl + (t * 2 + half) * 16);
+    float fwv[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (unit < O) acc += fw[r] * fmaxf(out[r], 0.0f);
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = fw[q];
+      fwv[4 * q] = v.x; fwv[4 * q + 1] = v.y; fwv[4 * q + 2] = v.z; fwv[4 * q + 3] = v.w;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += fwv[r] * relu_bits(out[r]);
   }
   acc += __shfl_xor(acc, 32, 64);
   if (m < M && half == 0) Y[m] = acc + ex.final_b;
+#ifdef EBC_VNS_TRACE
+  {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (lane == 0) trl[3] = t;  // (slot 3 of period 0: the wave's end)
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(const_cast<float *>(ex.row_weight));  // (unused by this block)
+    if (dbg && lane < P * 4) dbg[(size_t)tile * P * 4 + lane] = trl[lane];
+  }
+#endif
 }
 
 }  // namespace ebc

@@ -15,7 +15,11 @@ int launch(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, const 
            const ebc::MlpExtra &ex) {
   constexpr int NW = 8;
   constexpr size_t lds = 3 * (size_t)TH * 4096 + ((size_t)TH * 32 + 2 * (size_t)TO * 32) * 4 +
-                         (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH;
+                         (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH
+#ifdef EBC_VNS_TRACE
+                         + (size_t)NW * (TI + TO) * 4 * 8
+#endif
+      ;
   static bool raised[64] = {false};  // more than the 64 KB a launch gets by default; a function attribute is per device
   if (lds > 65536 && !raised[device & 63]) {
     HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

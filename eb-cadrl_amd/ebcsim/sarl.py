@@ -7,6 +7,8 @@ one ebc_lookahead launch that leaves rows_rotated[E][A][R][T] in HBM, and the va
 network is rebuilt functionally from the reference's state_dict, so its .pth files load as they
 are.  Rows beyond an env's n_humans + n_static are masked out of the mean / softmax (the
 reference never creates them)."""
+import contextlib
+
 import numpy as np
 import torch
 
@@ -342,6 +344,17 @@ class SarlValueNet(object):
         self.measured_coarse_err = err
         return self.coarse_eps
 
+    CHUNK_STREAMS = 2  # streams the chunks of a decision batch alternate between (1: the caller's stream only)
+
+    def _chunk_streams(self, device):
+        if self.CHUNK_STREAMS < 2:
+            return ()
+        pool = self.__dict__.setdefault("_side_streams", {})
+        key = (str(device), self.CHUNK_STREAMS)
+        if key not in pool:
+            pool[key] = tuple(torch.cuda.Stream(device=device) for _ in range(self.CHUNK_STREAMS))
+        return pool[key]
+
     def action_values(self, rows, reward, discount, n_valid=None, refine=None, chunk_pairs=None, eps=None):
         """reward + discount * V(rows) for every candidate action (multi_human_rl.py:72-76): rows
         [E, A, R, T] float32, reward [E, A] float64, n_valid [E] or None -> values [E, A] float64.
@@ -357,10 +370,26 @@ class SarlValueNet(object):
         E, A, R, T = rows.shape
         step = E if not chunk_pairs else max(1, int(chunk_pairs) // A)
         v = torch.empty((E, A), dtype=torch.float32, device=rows.device)
-        for e0 in range(0, E, step):
+        n_chunks = -(-E // step)
+        side = self._chunk_streams(rows.device) if (n_chunks > 1 and rows.is_cuda and self._native_blocks() is not None) else ()
+        if side:
+            # Chunks are independent, and a third of a chunk's kernels are small (the per-pair blocks: ~110 workgroups on
+            # 256 CUs, each as long as its own critical path): chunks alternate between two streams, so one chunk's
+            # small kernels run beside the other's wide ones.  An even number of equal chunks, no larger than asked for.
+            n_chunks += n_chunks & 1
+            step = -(-E // n_chunks)
+            main = torch.cuda.current_stream(rows.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+        for i, e0 in enumerate(range(0, E, step)):
             e1 = min(E, e0 + step)
-            nv = None if n_valid is None else n_valid[e0:e1].repeat_interleave(A)
-            v[e0:e1] = self.forward(rows[e0:e1].reshape(-1, R, T), nv).view(e1 - e0, A)
+            if side:
+                side[i % len(side)].wait_event(ready)
+            with torch.cuda.stream(side[i % len(side)]) if side else contextlib.nullcontext():
+                nv = None if n_valid is None else n_valid[e0:e1].repeat_interleave(A)
+                v[e0:e1] = self.forward(rows[e0:e1].reshape(-1, R, T), nv).view(e1 - e0, A)
+        for s_ in side:
+            main.wait_stream(s_)
         values = reward + discount * v.to(torch.float64)
         if not (rows.is_cuda and self._native_blocks() is not None) or refine == 0:
             return values

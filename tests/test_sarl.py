@@ -246,3 +246,28 @@ def test_decisions_are_the_float32_decisions_on_the_bench_workload():
           "refined vs torch float32 %.2e; vs the float64 network: native %.2e, torch float32 %.2e" % (
               st["candidates"] / st["decisions"], st["over2"], st["decisions"], st["max_set"], worst_coarse, worst_refined,
               worst_native64, worst_torch64))
+
+
+@pytest.mark.gpu
+def test_chunks_on_two_streams_give_the_values_of_one_stream():
+    """action_values spreads the chunks of a decision batch over two streams (one chunk's small per-pair kernels beside
+    the other's wide ones): every value must be the value of the single-stream pass, bit for bit — a pair's result does
+    not depend on where its rows lie in a batch — and the caller's stream must see them complete."""
+    import torch
+    from ebcsim.sarl import SarlValueNet
+    dev = torch.device("cuda", 0)
+    net = SarlValueNet.load(os.path.join(GOLDEN, "weights", "sarl_n10_ebcadrl.pth"), device=str(dev))
+    g = torch.Generator().manual_seed(21)
+    E, A, R, T = 37, 81, 18, 17
+    rows = torch.randn(E, A, R, T, generator=g).to(dev)
+    rows[..., 13:] = 0
+    rows[..., 13] = 1
+    reward = torch.randn(E, A, generator=g, dtype=torch.float64).to(dev)
+    nv = torch.randint(12, R + 1, (E,), generator=g).to(dev)
+    out = {}
+    for streams in (1, 2):
+        net.CHUNK_STREAMS = streams
+        for _ in range(2):  # the second pass re-uses the streams and the allocator's blocks of the first
+            out[streams] = net.action_values(rows, reward, 0.9, n_valid=nv, refine=0, chunk_pairs=5 * A)
+    assert torch.equal(out[1], out[2])
+    assert bool(torch.isfinite(out[2]).all())

@@ -38,6 +38,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     print("%d envs x %d actions, net %s: %.2f ms per decision batch = %.0f decisions/s" % (E, len(space), which, dt * 1e3, E / dt))
+    print("  coarse_eps %.3g, refine_stats %s" % (net.coarse_eps, getattr(net, "refine_stats", None)))
 
 
 if __name__ == "__main__":
