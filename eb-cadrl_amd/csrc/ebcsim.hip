@@ -981,6 +981,15 @@ int ebc_robot_orca_sim_state(void *handle, int location, int set, int32_t *rows,
   return EBC_OK;
 }
 
+// A step's launch carries per-call state (the double-buffered robot, the launch counter of the mailboxes): replayed
+// from a HIP graph it would run with the arguments of the capture.  Refused where it would be recorded.
+static int refuse_capture(Handle *h, const char *what) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(h->stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+    return fail(EBC_ERR_UNSUPPORTED, std::string(what) + ": the stream is being captured into a HIP graph; a step must be launched, not replayed");
+  return EBC_OK;
+}
+
 int ebc_step_k(void *handle, const EbcStepKArgs *a) {
   Handle *h;
   int rc = check_handle(handle, &h);
@@ -988,6 +997,7 @@ int ebc_step_k(void *handle, const EbcStepKArgs *a) {
   if (!a || a->struct_size != sizeof(EbcStepKArgs)) return fail(EBC_ERR_INVALID, "EbcStepKArgs.struct_size");
   if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_step_k before ebc_reset");
   if (h->faulted) return fail(EBC_ERR_STATE, "ebc_step_k: the handle reported a mailbox fault; ebc_reset re-arms it");
+  if ((rc = refuse_capture(h, "ebc_step_k")) != EBC_OK) return rc;
   if (a->K < 1) return fail(EBC_ERR_INVALID, "K");
   if (a->human_policy != EBC_HUMAN_ORCA && a->human_policy != EBC_HUMAN_LINEAR && a->human_policy != EBC_HUMAN_EXTERNAL)
     return fail(EBC_ERR_INVALID, "human_policy (a cached look-ahead holds for one step only)");
@@ -1070,6 +1080,7 @@ int ebc_step(void *handle, const EbcStepArgs *a) {
   if (!a || a->struct_size != sizeof(EbcStepArgs)) return fail(EBC_ERR_INVALID, "EbcStepArgs.struct_size");
   if (!h->has_reset) return fail(EBC_ERR_STATE, "ebc_step before ebc_reset");
   if (h->faulted) return fail(EBC_ERR_STATE, "ebc_step: the handle reported a mailbox fault; ebc_reset re-arms it");
+  if ((rc = refuse_capture(h, "ebc_step")) != EBC_OK) return rc;
   if (a->human_policy < EBC_HUMAN_EXTERNAL || a->human_policy > EBC_HUMAN_CACHED)
     return fail(EBC_ERR_INVALID, "human_policy");
   if (a->robot_policy == EBC_ROBOT_LINEAR && h->p.robot_kinematics != EBC_HOLONOMIC)

@@ -15,6 +15,18 @@ import torch
 from . import _abi
 
 
+def uniform_v_pref(env):
+    """The robots' preferred speed, which the whole batch must share: the reference builds the action space from it and
+    discounts by gamma^(dt * v_pref) PER ROBOT (multi_human_rl.py:36-60, 72-76); a batch here has one action space and
+    one discount, so robots that differ (a scene pool loaded from files can) are refused instead of silently taking
+    env 0's."""
+    v = np.asarray(env.get_state()["robot"], dtype=np.float64)[:, 7]
+    if float(v.min()) != float(v.max()):
+        raise ValueError("the robots of this batch differ in v_pref (%g .. %g): one action space and one discount per "
+                         "batch — split the batch by v_pref" % (float(v.min()), float(v.max())))
+    return float(v[0])
+
+
 def _mlp(x, layers, last_relu):
     """Linear (+ ReLU) stack.  On the GPU the bias and the ReLU ride in the GEMM's epilogue
     (torch._addmm_activation -> hipBLASLt): same values, no separate pass over the activations."""
@@ -603,7 +615,7 @@ class DeviceSarlPolicy(object):
             self._acts = torch.tensor(self.actions_np, dtype=torch.float64, device=dev)
             self._bufs = env.alloc_lookahead_outputs(A, ("reward", "rows_rotated"))
             self._n_valid = torch.full((env.E,), env.R, dtype=torch.int64, device=dev)
-            self._v_pref = float(env.get_state()["robot"][0, 7])
+            self._v_pref = uniform_v_pref(env)
         self.n_valid = None
         if getattr(env, "ragged", False):
             env.row_counts_device(self._n_valid)

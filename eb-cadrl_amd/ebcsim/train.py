@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import _abi
-from .sarl import SarlValueNet, _mlp
+from .sarl import SarlValueNet, _mlp, uniform_v_pref
 
 
 class SarlModule(torch.nn.Module):
@@ -347,7 +347,7 @@ def collect(env, policy, target_net, memory, steps, gamma, epsilon=0.0, generato
     cur = torch.zeros((E, R, T), dtype=torch.float32, device=dev)
     outs = env.alloc_step_outputs(("reward", "done", "info", "obs_rotated"))
     env.observe_device(cur)
-    v_pref = float(env.get_state()["robot"][0, 7])
+    v_pref = uniform_v_pref(env)
     gamma_bar = gamma ** (env.params.time_step * v_pref)
     A = len(policy.actions_np)
     total = 0.0
@@ -390,7 +390,7 @@ def collect_il(env, memory, steps, gamma, safety_space=0.0, human_policy=_abi.HU
     persistent_sim=False: the demonstrator sees every state's own radii (a fresh policy object per step)."""
     E, R, T = env.E, env.R, env.T
     env.robot_orca_sim(bool(persistent_sim))
-    v_pref = float(env.get_state()["robot"][0, 7])
+    v_pref = uniform_v_pref(env)
     gamma_bar = gamma ** (env.params.time_step * v_pref)
     ragged = bool(getattr(env, "ragged", False))
     # the whole window in ONE call through the C ABI (ebc_step_k): per step the library enqueues the state the
@@ -553,7 +553,7 @@ def evaluate(env, decide, gamma, max_steps=None, human_policy=_abi.HUMAN_ORCA):
     limit = float(env.params.time_limit)
     steps = int(max_steps or round(limit / dt) + 2)
     outs = env.alloc_step_outputs(("reward", "done", "info", "dmin"))
-    v_pref = float(env.get_state()["robot"][0, 7])
+    v_pref = uniform_v_pref(env)
     gamma_bar = gamma ** (dt * v_pref)
     dd = torch.tensor(list(env.params.discomfort_dist), dtype=torch.float64, device=dev)  # adult, bicycle, child
     alive = torch.ones(E, dtype=torch.bool, device=dev)

@@ -318,7 +318,8 @@ int ebc_robot_orca_sim_state(void *handle, int location, int set, int32_t *rows,
 /* One env.step for every env (simulator/env.py:388-466), enqueued on the handle's stream.  With
  * EBC_HUMAN_ORCA it is ONE kernel launch whose arguments change from call to call (the robot state
  * is double-buffered and a launch counter travels with the launch): call it once per step; do not
- * capture it in a HIP graph and replay it.  A broken hand-off inside that launch (never seen)
+ * capture it in a HIP graph and replay it (a call on a stream under capture returns EBC_ERR_UNSUPPORTED and
+ * records nothing).  A broken hand-off inside that launch (never seen)
  * surfaces as EBC_ERR_DEVICE — not as a hang — from ebc_synchronize or from the next host-location
  * call (whose copy-back carries the fault word); it is reported once, the handle then refuses
  * steps (EBC_ERR_STATE) until ebc_reset has re-armed it. */

@@ -690,3 +690,34 @@ def test_robot_orca_rollouts_vs_oracle(fixture, E, steps, safety):
         _compare_step(og, oo, "%s step %d" % (fixture, t))
         kinds.update(og["info"].tolist())
     assert len(kinds) >= 2
+
+
+@pytest.mark.gpu
+def test_step_on_a_capturing_stream_is_refused():
+    """A step's launch carries per-call state (the double-buffered robot, the mailboxes' launch counter): replayed from
+    a HIP graph it would run with the capture's arguments.  ebc_step on a stream under capture must return
+    EBC_ERR_UNSUPPORTED, record nothing, and leave the handle usable afterwards."""
+    import torch
+    from ebcsim import _capi
+    from ebcsim.batched import BatchedEnv
+    import bench
+    params, batch = bench.build_batch("metric", 64, 0)
+    env = BatchedEnv(params, 64, batch.N, batch.S)
+    env.reset(batch)
+    outs = env.alloc_step_outputs(("reward", "done"))
+    act = torch.zeros((64, 2), dtype=torch.float64, device="cuda:0")
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        env.use_torch_stream()
+        env.step_device(outs, robot_action=act, human_policy=_abi.HUMAN_ORCA)
+        side.synchronize()
+        graph.capture_begin()
+        try:
+            with pytest.raises(_capi.EbcError, match="captured"):
+                env.step_device(outs, robot_action=act, human_policy=_abi.HUMAN_ORCA)
+        finally:
+            graph.capture_end()
+        env.step_device(outs, robot_action=act, human_policy=_abi.HUMAN_ORCA)
+        side.synchronize()
+    assert bool(torch.isfinite(outs["reward"]).all())

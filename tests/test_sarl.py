@@ -271,3 +271,21 @@ def test_chunks_on_two_streams_give_the_values_of_one_stream():
             out[streams] = net.action_values(rows, reward, 0.9, n_valid=nv, refine=0, chunk_pairs=5 * A)
     assert torch.equal(out[1], out[2])
     assert bool(torch.isfinite(out[2]).all())
+
+
+def test_batches_whose_robots_differ_in_v_pref_are_refused():
+    """One action space and one discount gamma^(dt v_pref) per batch (the reference has them per robot,
+    multi_human_rl.py:36-60, 72-76): a batch of robots with different v_pref must not silently take env 0's."""
+    from ebcsim.sarl import uniform_v_pref
+
+    class Env:
+        def __init__(self, v):
+            self.v = v
+
+        def get_state(self):
+            robot = np.zeros((len(self.v), 9))
+            robot[:, 7] = self.v
+            return {"robot": robot}
+    assert uniform_v_pref(Env([1.0, 1.0, 1.0])) == 1.0
+    with pytest.raises(ValueError, match="v_pref"):
+        uniform_v_pref(Env([1.0, 1.2, 1.0]))
