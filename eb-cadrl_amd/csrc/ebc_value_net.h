@@ -366,18 +366,30 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
     typedef double __attribute__((address_space(3))) *LdsD;
     const LdsF ytf = (LdsF)yt;
     const LdsD ytd = (LdsD)yt;
-    int bnd = 16, seg_lo = 0;
+    int seg_lo = 0;
     if (reduce) {
+      // Row r's weight is parked TWICE in the spare bytes, as the pair (w, 0) if the row belongs to the first group its
+      // 16-row half meets and (0, w) if to the second: the column walk below is then two fused multiply-adds per row
+      // (the product of two float32 is exact in float64, so fma(w, y, a) IS a + w * y) instead of a multiply, two adds
+      // and four 32-bit selects.
       if (lane < 32) {
-        const int row = m0 + lane;
-        ytd[(lane * EBC_VN_XROW + 128) / 8] = row < M ? (ex.row_weight ? (double)ex.row_weight[row] : 1.0) : 0.0;
+        const int row = m0 + lane, hrow0 = m0 + (lane & 16);
+        const int hnext = (hrow0 / ex.seg_rows + 1) * ex.seg_rows - hrow0;  // rows of this row's half before the next group starts
+        const double w = row < M ? (ex.row_weight ? (double)ex.row_weight[row] : 1.0) : 0.0;
+        const bool first = (lane & 15) < hnext;
+        ytd[(lane * EBC_VN_XROW + 128) / 8] = first ? w : 0.0;
+        ytd[(lane * EBC_VN_XROW + 136) / 8] = first ? 0.0 : w;
       }
       const int row0 = m0 + 16 * half, s0 = row0 / ex.seg_rows;
       seg_lo = s0 - m0 / ex.seg_rows;
-      const int next = (s0 + 1) * ex.seg_rows - row0;  // rows of this half before the next group starts
-      bnd = next < 16 ? next : 16;
       __builtin_amdgcn_wave_barrier();
     }
+    // relu_out as the lower bound of ONE integer max on the bits (0: ReLU; INT_MIN: the value as it is)
+    const int relu_lo = relu_out ? 0 : (int)0x80000000;
+    auto act = [&](float v) {
+      const int b = __float_as_int(v);
+      return __int_as_float(b > relu_lo ? b : relu_lo);
+    };
     const bool store = ex.store_y != 0 || !reduce;
     // a workgroup's last waves can lie past the last row tile: they own no tile of the outputs that are kept per tile
     uint4 *fout = (ex.frag_out && m0 < M) ? ex.frag_out + (size_t)(m0 >> 5) * TO * 4 * PART + lane : nullptr;
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
       for (int g = 0; g < 4; ++g) {
         vn_f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = relu_out ? relu_bits(out[t][0][4 * g + c]) : out[t][0][4 * g + c];
+        for (int c = 0; c < 4; ++c) v[c] = act(out[t][0][4 * g + c]);
         yt[(col * EBC_VN_XROW + (8 * g + 4 * half) * 4) / 16] = v;  // units 8 g + 4 half .. + 3 of row `col`
       }
       __builtin_amdgcn_wave_barrier();
@@ -413,9 +425,9 @@ __global__ __launch_bounds__(64 * NW, ((LEAN || (TI + TO) * 16 + 64 <= 256) ? 2 
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int r = 16 * half + i;
-          const double pv = ytd[(r * EBC_VN_XROW + 128) / 8] * (double)ytf[(r * EBC_VN_XROW) / 4 + col];
-          a0 += i < bnd ? pv : 0.0;
-          a1 += i < bnd ? 0.0 : pv;
+          const double y = (double)ytf[(r * EBC_VN_XROW) / 4 + col];
+          a0 = __builtin_fma(ytd[(r * EBC_VN_XROW + 128) / 8], y, a0);
+          a1 = __builtin_fma(ytd[(r * EBC_VN_XROW + 136) / 8], y, a1);
         }
         const int unit = t * 32 + col;
 #pragma unroll

@@ -26,6 +26,7 @@ def main():
     env.use_torch_stream()
     net = SarlValueNet.load(os.path.join(ROOT, "tests", "golden", "weights", which + ".pth"), device="cuda")
     net.frag_handoff = os.environ.get("EBCSIM_FRAG_HANDOFF", "1") != "0"
+    net.CHUNK_STREAMS = int(os.environ.get("EBCSIM_CHUNK_STREAMS", net.CHUNK_STREAMS))  # 1: per-kernel times without overlap
     space = actions.build_action_space(float(batch.robot[0, 7]))
     pol = DeviceSarlPolicy(net, space, 0.9, chunk_rows=int(os.environ.get("EBCSIM_CHUNK_ROWS", 1 << 19)))
     outs = env.alloc_step_outputs(("reward", "done"))
