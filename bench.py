@@ -342,6 +342,7 @@ def also_kernels(env, batch, dev, cfg_s=None):
         # architecture of the reference's shipped eb-cadrl weights, data/eb-cadrl/policy_x2_agent_type.config;
         # random-init weights) on 1024 x 81 pairs x R rows + float32 refinement of the near-best candidates + argmax
         # (rl/policy/multi_human_rl.py:38-80, rl/policy/sarl.py:38-82)
+        from ebcsim import _capi
         from ebcsim.batched import BatchedEnv
         from ebcsim.sarl import DeviceSarlPolicy, SarlValueNet
         from ebcsim.train import SarlModule
@@ -363,10 +364,18 @@ def also_kernels(env, batch, dev, cfg_s=None):
         pair_macs = 200 * 200 + (6 + 100) * 300 + 300 * 200 + 200 * 200 + 200
         macs = float(Ed) * A * (R * row_macs + pair_macs)
         tf = 3.0 * 2.0 * macs / (ms * 1e-3) / 1e12  # three bf16 MFMA products per float32 product
+        busy = None  # matrix-pipe occupancy per block, PMC-measured (tools/collect_value_net_pmc.sh), for THESE kernel sources only
+        try:
+            bj = json.load(open(os.path.join(ROOT, "profiles", "value_net_mfma_busy.json")))
+            busy = ({k.replace("ebc::", ""): v["mfma_busy"] for k, v in bj["kernels"].items()} if bj.get("csrc_sha256") == _capi.csrc_sha256()
+                    else "profiles/value_net_mfma_busy.json was taken on other kernel sources: not reported")
+        except (OSError, ValueError, KeyError):
+            pass
         out.append({"kernel": "decision: %d envs x %d actions x %d rows, look-ahead sweep + SARL x2 network (split-bf16 MFMA "
                               "blocks with the pair mean / attention sum in their epilogues) + float32 re-evaluation (ebc_mlp2_forward_f32) of every candidate within the blocks' error bound of the best + argmax" % (Ed, A, R),
                     "ms_per_decision_batch": ms, "decisions_per_s": Ed / (ms * 1e-3),
                     "native_blocks": bool(net._native_blocks()), "refine_stats": getattr(net, "refine_stats", None),
+                    "mfma_busy_per_block": busy,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                  "frac": tf / MFMA_BF16_PEAK_TFLOPS, "f32_equivalent_tflops": tf / 3.0,
                                  "algorithmic_macs_per_batch": macs}})

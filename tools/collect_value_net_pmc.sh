@@ -7,6 +7,7 @@ root=$PWD
 out=$root/gpurun_out/vn_pmc_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+export EBCSIM_CHUNK_STREAMS=1  # one stream: per-kernel times and counters without overlap
 B="python3 $root/tools/sarl_profile.py 1024"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o kt -- $B > $out/kt.log 2>&1
 i=0
@@ -19,5 +20,5 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM
 done
 python3 $root/profiles/summarize_pmc.py $out/p*/*counter_collection.csv > $out/pmc.json
 cd $root
-python3 tools/value_net_pmc_table.py $out/pmc.json $out/kt > $out/table.txt
+python3 tools/value_net_pmc_table.py $out/pmc.json $out/kt $out/value_net_mfma_busy.json > $out/table.txt
 cat $out/table.txt
