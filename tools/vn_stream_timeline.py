@@ -42,7 +42,7 @@ def main():
     nxt = np.concatenate([t[:, 1:, 0], t[:, :1, 3]], axis=1)
     compute = nxt - t[:, :, 2]
     life = t[:, 0, 3] - t[:, 0, 0]
-    print("waves %d; s_memtime ticks (~0.74 shader cycles each here: compare the sum with launch time / rounds) per period: median [p10 .. p90]" % len(t))
+    print("waves %d; s_memtime ticks (shader cycles; 1.98 GHz under matrix load, tools/mfma_rate.hip) per period: median [p10 .. p90]" % len(t))
     for p in range(P):
         def q(a):
             return "%5.0f [%4.0f .. %5.0f]" % (np.median(a[:, p]), np.percentile(a[:, p], 10), np.percentile(a[:, p], 90))
