@@ -47,9 +47,12 @@ __device__ __forceinline__ void vm_wait() {  // at most N vector-memory operatio
 
 // TI / TH / TO: input / hidden / output tiles; KIN / KH: the input (hidden) width ends in the first half of its last
 // tile: that tile's second k-step multiplies zeros and is left out.
-template <int TI, int TH, int TO, int NW, int KIN, int KH>
-__global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLayer L1, PackedLayer L2, float *Y, int O, MlpExtra ex) {
-  extern __shared__ uint4 sbuf[];  // slab ring [3][TH][2][2][64] | hidden bias | output bias | third layer | group terms
+// GROUP: the pair's group term is added to the hidden pre-activation (the attention stack).  FINAL: a one-output third
+// layer finishes every output tile on the spot (y [M]); else the tile goes through the pair-sum epilogue of the general
+// block (MlpExtra.partial / row_weight / seg_rows: `mlp2`, whose rows are never written), one tile per period.
+template <int TI, int TH, int TO, int NW, int KIN, int KH, bool GROUP, bool FINAL>
+__global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLayer L1, PackedLayer L2, float *Y, int O, MlpExtra ex, int relu_out) {
+  extern __shared__ uint4 sbuf[];  // slab ring [3][TH][2][2][64] | hidden bias | output bias | third layer | group terms | output tiles
   constexpr int PART = 64, SLAB = TH * 4 * PART, PIECES = TH * 4;
   constexpr int NST = (PIECES + NW - 1) / NW;  // staging instructions per wave and slab (the last waves repeat the last piece)
   constexpr int P = TI + TO;                   // periods
@@ -57,10 +60,17 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
   const int tile = blockIdx.x * NW + wave, m0w = tile * 32, m = m0w + col;
   float *hbias = reinterpret_cast<float *>(sbuf + 3 * SLAB), *obias = hbias + TH * 32, *fwl = obias + TO * 32;
   const LdsF4 gt = (LdsF4)(reinterpret_cast<unsigned char *>(fwl + TO * 32) + (size_t)wave * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH);
+  // the wave's parked output tile of the pair-sum epilogue: 32 rows x 144 bytes (128 of the tile + the row's weight pair)
+  constexpr size_t GT_BYTES = GROUP ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0;
+  const LdsF4 yt = (LdsF4)(reinterpret_cast<unsigned char *>(fwl + TO * 32) + GT_BYTES + (size_t)wave * 32 * EBC_VN_XROW);
+  typedef float __attribute__((address_space(3))) *LdsF;
+  typedef double __attribute__((address_space(3))) *LdsD;
+  const LdsF ytf = (LdsF)yt;
+  const LdsD ytd = (LdsD)yt;
 #ifdef EBC_VNS_TRACE  // measurement build (tools/vn_stream_timeline.py): per wave and period, the clock before the
                       // counted wait, after it, after the barrier
   unsigned long long *trl = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(fwl + TO * 32) +
-                                                                   (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH) + (size_t)wave * P * 4;
+                                                                   GT_BYTES + (FINAL ? 0 : (size_t)NW * 32 * EBC_VN_XROW)) + (size_t)wave * P * 4;
   auto stamp = [&](int p, int k) {
     const unsigned long long t = __builtin_amdgcn_s_memtime();
     if (lane == 0) trl[p * 4 + k] = t;
@@ -106,11 +116,25 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
   for (int q = threadIdx.x; q < TH * 32; q += 64 * NW) hbias[q] = L1.bias[q];
   for (int q = threadIdx.x; q < TO * 32; q += 64 * NW) {
     obias[q] = L2.bias[q];
-    const int t = q >> 5, hh = (q >> 4) & 1, r = q & 15, unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    fwl[q] = unit < O ? ex.final_w[unit] : 0.0f;
+    if (FINAL) {
+      const int t = q >> 5, hh = (q >> 4) & 1, r = q & 15, unit = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      fwl[q] = unit < O ? ex.final_w[unit] : 0.0f;
+    }
   }
   const int Hp = (ex.H + 3) & ~3;  // floats per parked row
-  {
+  int seg_lo = 0;
+  if (!FINAL) {  // the rows' weights, as (w, 0) / (0, w) by the group a row belongs to (the general block's epilogue)
+    if (lane < 32) {
+      const int row = m0w + lane, hrow0 = m0w + (lane & 16);
+      const int hnext = (hrow0 / ex.seg_rows + 1) * ex.seg_rows - hrow0;
+      const double w = row < M ? (ex.row_weight ? (double)ex.row_weight[row] : 1.0) : 0.0;
+      const bool first = (lane & 15) < hnext;
+      ytd[(lane * EBC_VN_XROW + 128) / 8] = first ? w : 0.0;
+      ytd[(lane * EBC_VN_XROW + 136) / 8] = first ? 0.0 : w;
+    }
+    seg_lo = (m0w + 16 * half) / ex.seg_rows - m0w / ex.seg_rows;
+  }
+  if (GROUP) {
     const int first = m0w / ex.group_rows;
     const int groups_total = (M + ex.group_rows - 1) / ex.group_rows;
     for (int q = lane; q < EBC_VN_GROUPS * (Hp / 4); q += 64) {
@@ -120,7 +144,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
       gt[(gq * EBC_VN_GROUP_PITCH) / 16 + c4] = v;
     }
   }
-  const int g_local = m < M ? m / ex.group_rows - m0w / ex.group_rows : -1;
+  const int g_local = (GROUP && m < M) ? m / ex.group_rows - m0w / ex.group_rows : -1;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue: the loads of periods 0 and 1
   xload(IntC<0>{});
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
   for (int u = 0; u < TH; ++u) {
     f32x16 hid = hacc[u];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < (GROUP ? 4 : 0); ++g) {
       const int unit = u * 32 + 8 * g + 4 * half;
       const bool on = g_local >= 0 && unit + 3 < Hp;  // (read always, from a parked row; selected afterwards: no branch per piece)
       const vn_f32x4 t = gt[((on ? g_local : 0) * EBC_VN_GROUP_PITCH) / 16 + (unit + 3 < Hp ? unit / 4 : 0)];
@@ -247,18 +271,53 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
     // the third layer's share of this tile: units in register order, like the general block.  Its weights are read as
     // four 16-byte pieces and every product is added — the padding units' weights are parked as 0 and their outputs
     // are finite, so they add +0 — : a test per unit was a branch and a 4-byte LDS read apiece, 16 latencies in a row.
-    const float4 *fw = reinterpret_cast<const float4 *>(fwl + (t * 2 + half) * 16);
-    float fwv[16];
+    if constexpr (FINAL) {
+      const float4 *fw = reinterpret_cast<const float4 *>(fwl + (t * 2 + half) * 16);
+      float fwv[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = fw[q];
-      fwv[4 * q] = v.x; fwv[4 * q + 1] = v.y; fwv[4 * q + 2] = v.z; fwv[4 * q + 3] = v.w;
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = fw[q];
+        fwv[4 * q] = v.x; fwv[4 * q + 1] = v.y; fwv[4 * q + 2] = v.z; fwv[4 * q + 3] = v.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc += fwv[r] * relu_bits(out[r]);
+    } else {
+      // the general block's pair-sum epilogue on this tile (ebc_value_net.h): parked in the wave's LDS tile, lane
+      // (unit, half) walks its column over 16 rows with the rows' weight pairs — the same float64 sums
+      const int relu_lo = relu_out ? 0 : (int)0x80000000;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        vn_f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int b = __float_as_int(out[4 * g + c]);
+          v[c] = __int_as_float(b > relu_lo ? b : relu_lo);
+        }
+        yt[(col * EBC_VN_XROW + (8 * g + 4 * half) * 4) / 16] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = 16 * half + i;
+        const double y = (double)ytf[(r * EBC_VN_XROW) / 4 + col];
+        a0 = __builtin_fma(ytd[(r * EBC_VN_XROW + 128) / 8], y, a0);
+        a1 = __builtin_fma(ytd[(r * EBC_VN_XROW + 136) / 8], y, a1);
+      }
+      const int unit = t * 32 + col;
+#pragma unroll
+      for (int sg = 0; sg < EBC_VN_SEGS; ++sg) {
+        double c = (seg_lo == sg ? a0 : 0.0) + (seg_lo + 1 == sg ? a1 : 0.0);
+        c += __shfl_xor(c, 32, 64);
+        if (half == 0 && unit < O && m0w < M) ex.partial[((size_t)(m0w >> 5) * EBC_VN_SEGS + sg) * O + unit] = c;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc += fwv[r] * relu_bits(out[r]);
   }
-  acc += __shfl_xor(acc, 32, 64);
-  if (m < M && half == 0) Y[m] = acc + ex.final_b;
+  if constexpr (FINAL) {
+    acc += __shfl_xor(acc, 32, 64);
+    if (m < M && half == 0) Y[m] = acc + ex.final_b;
+  }
 #ifdef EBC_VNS_TRACE
   {
     const unsigned long long t = __builtin_amdgcn_s_memtime();

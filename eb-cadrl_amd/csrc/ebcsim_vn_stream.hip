@@ -10,42 +10,53 @@ namespace ebc_host {
 
 namespace {
 
-template <int TI, int TH, int TO, int KIN, int KH>
+template <int TI, int TH, int TO, int KIN, int KH, bool GROUP, bool FINAL>
 int launch(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, const ebc::PackedLayer &L2, int O, float *y,
-           const ebc::MlpExtra &ex) {
+           const ebc::MlpExtra &ex, int relu_out) {
   constexpr int NW = 8;
   constexpr size_t lds = 3 * (size_t)TH * 4096 + ((size_t)TH * 32 + 2 * (size_t)TO * 32) * 4 +
-                         (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH
+                         (GROUP ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0) + (FINAL ? 0 : (size_t)NW * 32 * EBC_VN_XROW)
 #ifdef EBC_VNS_TRACE
                          + (size_t)NW * (TI + TO) * 4 * 8
 #endif
       ;
   static bool raised[64] = {false};  // more than the 64 KB a launch gets by default; a function attribute is per device
   if (lds > 65536 && !raised[device & 63]) {
-    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH, GROUP, FINAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised[device & 63] = true;
   }
   const dim3 grid((unsigned)((M + 32 * NW - 1) / (32 * NW))), block(64 * NW);
-  hipLaunchKernelGGL((ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH>), grid, block, lds, st, M, L1, L2, y, O, ex);
+  hipLaunchKernelGGL((ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH, GROUP, FINAL>), grid, block, lds, st, M, L1, L2, y, O, ex, relu_out);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
+}
+
+template <int TO, bool GROUP, bool FINAL>
+int launch_k(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, const ebc::PackedLayer &L2, int K0, int H, int O, float *y,
+             const ebc::MlpExtra &ex, int relu_out) {
+  const bool kin = K0 <= 32 * 7 - 16, kh = H <= 32 * 7 - 16;
+  if (kin && kh) return launch<7, 7, TO, 1, 1, GROUP, FINAL>(device, st, M, L1, L2, O, y, ex, relu_out);
+  if (kin) return launch<7, 7, TO, 1, 0, GROUP, FINAL>(device, st, M, L1, L2, O, y, ex, relu_out);
+  if (kh) return launch<7, 7, TO, 0, 1, GROUP, FINAL>(device, st, M, L1, L2, O, y, ex, relu_out);
+  return launch<7, 7, TO, 0, 0, GROUP, FINAL>(device, st, M, L1, L2, O, y, ex, relu_out);
 }
 
 }  // namespace
 
 int vn_stream_launch(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, const ebc::PackedLayer &L2, int K0, int H, int O,
-                     float *y, const ebc::MlpExtra &ex) {
+                     float *y, const ebc::MlpExtra &ex, int relu_out) {
   static const bool off = [] { const char *e = getenv("EBCSIM_VN_STREAM"); return e && atoi(e) == 0; }();  // measurements: the general block
-  if (off) return EBC_VN_STREAM_NA;
+  if (off || !ex.frag_in || ex.frag_out) return EBC_VN_STREAM_NA;
+  if (L1.in_tiles != 7 || L1.out_tiles != 7) return EBC_VN_STREAM_NA;
   // the attention block as SarlValueNet calls it: fragment input, the pair's group term, a one-output third layer
-  if (!ex.frag_in || !ex.row_bias || !ex.final_w || ex.partial || ex.frag_out || !y) return EBC_VN_STREAM_NA;
-  if ((ex.H & 3) || ex.group_rows <= 0 || 31 / ex.group_rows + 2 > EBC_VN_GROUPS) return EBC_VN_STREAM_NA;  // group terms parked in LDS
-  if (L1.in_tiles != 7 || L1.out_tiles != 7 || L2.out_tiles != 7) return EBC_VN_STREAM_NA;
-  const bool kin = K0 <= 32 * 7 - 16, kh = H <= 32 * 7 - 16;
-  if (kin && kh) return launch<7, 7, 7, 1, 1>(device, st, M, L1, L2, O, y, ex);
-  if (kin) return launch<7, 7, 7, 1, 0>(device, st, M, L1, L2, O, y, ex);
-  if (kh) return launch<7, 7, 7, 0, 1>(device, st, M, L1, L2, O, y, ex);
-  return launch<7, 7, 7, 0, 0>(device, st, M, L1, L2, O, y, ex);
+  if (ex.row_bias && ex.final_w && !ex.partial && y && L2.out_tiles == 7) {
+    if ((ex.H & 3) || ex.group_rows <= 0 || 31 / ex.group_rows + 2 > EBC_VN_GROUPS) return EBC_VN_STREAM_NA;  // group terms parked in LDS
+    return launch_k<7, true, true>(device, st, M, L1, L2, K0, H, O, y, ex, relu_out);
+  }
+  // `mlp2` as SarlValueNet calls it: fragment input, the attention-weighted sums of its rows, the rows never written
+  if (!ex.row_bias && !ex.final_w && ex.partial && !y && !ex.store_y && L2.out_tiles == 4 && ex.seg_rows >= 16 && (O & 3) == 0)
+    return launch_k<4, false, false>(device, st, M, L1, L2, K0, H, O, y, ex, relu_out);
+  return EBC_VN_STREAM_NA;
 }
 
 }  // namespace ebc_host

@@ -312,3 +312,47 @@ def test_streamed_attention_block_equals_the_general_block_bit_for_bit():
             torch.cuda.synchronize()
             assert torch.equal(a, b), (K0, H, O, M, float((a - b).abs().max()))
             assert bool(torch.isfinite(a).all()) and float(a.abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_streamed_feature_block_equals_the_general_block_to_rounding():
+    """`mlp2` at 7 x 7 x 4 tiles (fragment input, its rows only as attention-weighted pair sums) runs as the streamed
+    kernel too.  Its hidden tiles add up in ONE chain where the general block alternates two, so the sums differ in the
+    last bits: both are held against a float64 evaluation of the same rows, the streamed one must be as close as the
+    general one; and whole copies of a pair anywhere in the batch still get bit-identical sums."""
+    from ebcsim.sarl import SarlValueNet, _NativeMlp2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(12)
+    R = 18
+    for K0, H, O in ((200, 200, 100), (224, 212, 128)):
+        def lin(o, i):
+            return torch.randn(o, i, generator=g) / i ** 0.5, torch.randn(o, generator=g)
+        l0, l1 = lin(64, 17), lin(K0, 64)
+        src = _NativeMlp2([l0, l1], 0)
+        w1, w2 = lin(H, K0), lin(O, H)
+        blk = _NativeMlp2([w1, w2], 0, in_fragments=True)
+        for B in (600, 57, 1):
+            M = B * R
+            pair = torch.randn(R, 17, generator=g)
+            x = torch.randn(M, 17, generator=g)
+            if B > 40:
+                x[7 * R:8 * R] = pair
+                x[33 * R:34 * R] = pair  # the same pair at another place of the batch (another tile alignment)
+            x = x.to(dev)
+            frag = _NativeMlp2.frag_buffer(M, K0, dev)
+            rows, _ = src.forward_ex(M, True, x=x, want_y=True, seg_rows=R, want_partial=True, frag_out=frag)
+            w = torch.rand(M, generator=g).to(dev)
+            if B > 40:
+                w[33 * R:34 * R] = w[7 * R:8 * R]
+            out = {}
+            for general in (False, True):
+                _, part = blk.forward_ex(M, False, frag_in=frag, want_y=False, seg_rows=R, row_weight=w, want_partial=True, general=general)
+                out[general] = SarlValueNet._pair_combine(part, None, B, R, False)
+            torch.cuda.synchronize()
+            h = torch.relu(torch.nn.functional.linear(rows.double().cpu(), w1[0].double(), w1[1].double()))
+            yref = torch.nn.functional.linear(h, w2[0].double(), w2[1].double())
+            ref = (yref * w.double().cpu()[:, None]).view(B, R, O).sum(1)
+            es, eg = float((out[False].double().cpu() - ref).abs().max()), float((out[True].double().cpu() - ref).abs().max())
+            assert es <= max(2.0 * eg, 1e-5 * max(1.0, float(ref.abs().max()))), (K0, H, O, B, es, eg)
+            if B > 40:
+                assert torch.equal(out[False][7], out[False][33])
