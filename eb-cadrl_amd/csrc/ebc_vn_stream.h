@@ -50,8 +50,13 @@ __device__ __forceinline__ void vm_wait() {  // at most N vector-memory operatio
 // GROUP: the pair's group term is added to the hidden pre-activation (the attention stack).  FINAL: a one-output third
 // layer finishes every output tile on the spot (y [M]); else the tile goes through the pair-sum epilogue of the general
 // block (MlpExtra.partial / row_weight / seg_rows: `mlp2`, whose rows are never written), one tile per period.
-template <int TI, int TH, int TO, int NW, int KIN, int KH, bool GROUP, bool FINAL>
-__global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLayer L1, PackedLayer L2, float *Y, int O, MlpExtra ex, int relu_out) {
+// ROWS: the input is float32 rows X [M][K0] (one input tile: `mlp1` on the 17-float observation rows), split by the lanes
+// in the head, natural k order; else the fragment tensor MlpExtra.frag_in.  Not FINAL: the tile can also leave as the
+// next block's fragments (MlpExtra.frag_out).
+template <int TI, int TH, int TO, int NW, int KIN, int KH, bool GROUP, bool FINAL, bool ROWS = false>
+__global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLayer L1, PackedLayer L2, float *Y, int O, MlpExtra ex, int relu_out,
+                                                                 const float *X, int K0) {
+  static_assert(!ROWS || (TI == 1 && !KIN), "row input: one input tile");
   extern __shared__ uint4 sbuf[];  // slab ring [3][TH][2][2][64] | hidden bias | output bias | third layer | group terms | output tiles
   constexpr int PART = 64, SLAB = TH * 4 * PART, PIECES = TH * 4;
   constexpr int NST = (PIECES + NW - 1) / NW;  // staging instructions per wave and slab (the last waves repeat the last piece)
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
   };
   // the wave's input fragments: [row tile][input tile][k-step][hi, lo][lane] (a tile past M reads tile 0: the tensor has
   // ceil(M / 32) tiles)
-  const uint4 *xsrc = ex.frag_in + (m0w < M ? (size_t)tile * TI * 4 * PART : 0) + lane;
+  const uint4 *xsrc = ROWS ? nullptr : ex.frag_in + (m0w < M ? (size_t)tile * TI * 4 * PART : 0) + lane;
   vn_u32x4 xr[3][4];  // (a register vector type: asm operands)
   auto xload = [&](auto ic) {
     constexpr int p = decltype(ic)::value;
@@ -147,7 +152,23 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
   const int g_local = (GROUP && m < M) ? m / ex.group_rows - m0w / ex.group_rows : -1;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- prologue: the loads of periods 0 and 1
-  xload(IntC<0>{});
+  if constexpr (ROWS) {  // this lane's row, the 8 columns of its half per k-step: element j of k-step s is k = 16 s + 8 half + j
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kk = 16 * s2 + 8 * half + j;
+        v[j] = (m < M && kk < K0) ? X[(size_t)m * K0 + kk] : 0.0f;
+      }
+      const Frag2 f = split8(v);
+      xr[0][2 * s2] = *reinterpret_cast<const vn_u32x4 *>(&f.hi);
+      xr[0][2 * s2 + 1] = *reinterpret_cast<const vn_u32x4 *>(&f.lo);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    xload(IntC<0>{});
+  }
   stage(0);
   if constexpr (TI > 1) xload(IntC<1>{});
   stage(1);
@@ -285,6 +306,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp2_stream_kernel(int M, PackedLa
       // the general block's pair-sum epilogue on this tile (ebc_value_net.h): parked in the wave's LDS tile, lane
       // (unit, half) walks its column over 16 rows with the rows' weight pairs — the same float64 sums
       const int relu_lo = relu_out ? 0 : (int)0x80000000;
+      if (ex.frag_out && m0w < M) {  // the tile as the next block's B fragments: 4 x 16 bytes per lane, 1 KB per store instruction
+        uint4 *fout = ex.frag_out + ((size_t)(m0w >> 5) * TO + t) * 4 * PART + lane;
+        Frag2 of[2];
+        tile_frags(out, relu_out != 0, of);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          fout[(s2 * 2) * PART] = *reinterpret_cast<const uint4 *>(&of[s2].hi);
+          fout[(s2 * 2 + 1) * PART] = *reinterpret_cast<const uint4 *>(&of[s2].lo);
+        }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         vn_f32x4 v;

@@ -11,6 +11,6 @@ namespace ebc_host {
 // general block); anything else: an error (ebc_last_error()).
 #define EBC_VN_STREAM_NA (-1000)
 int vn_stream_launch(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, const ebc::PackedLayer &L2, int K0, int H, int O,
-                     float *y, const ebc::MlpExtra &ex, int relu_out);
+                     float *y, const ebc::MlpExtra &ex, int relu_out, const float *x);
 
 }  // namespace ebc_host

@@ -373,7 +373,7 @@ int ebc_mlp2_forward_ex(void *mlp, void *stream, const EbcMlpArgs *a) {
     return fail(EBC_ERR_UNSUPPORTED, "mlp2 forward_ex: frag_out comes with partial sums (the tile epilogue)");
   }
   if (!(a->flags & EBC_MLP_GENERAL_KERNEL)) {  // the attention block at its widest: the streamed kernel (ebc_vn_stream.h)
-    const int rc = ebc_host::vn_stream_launch(m->device, (hipStream_t)stream, a->M, m->L1, m->L2, m->K0, m->H, m->O, a->y, ex, a->relu_out);
+    const int rc = ebc_host::vn_stream_launch(m->device, (hipStream_t)stream, a->M, m->L1, m->L2, m->K0, m->H, m->O, a->y, ex, a->relu_out, a->x);
     if (rc != EBC_VN_STREAM_NA) return rc;
   }
   return mlp2_dispatch(m, (hipStream_t)stream, a->x, a->M, a->relu_out, a->y, ex);

@@ -10,9 +10,9 @@ namespace ebc_host {
 
 namespace {
 
-template <int TI, int TH, int TO, int KIN, int KH, bool GROUP, bool FINAL>
+template <int TI, int TH, int TO, int KIN, int KH, bool GROUP, bool FINAL, bool ROWS = false>
 int launch(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, const ebc::PackedLayer &L2, int O, float *y,
-           const ebc::MlpExtra &ex, int relu_out) {
+           const ebc::MlpExtra &ex, int relu_out, const float *x = nullptr, int K0 = 0) {
   constexpr int NW = 8;
   constexpr size_t lds = 3 * (size_t)TH * 4096 + ((size_t)TH * 32 + 2 * (size_t)TO * 32) * 4 +
                          (GROUP ? (size_t)NW * EBC_VN_GROUPS * EBC_VN_GROUP_PITCH : 0) + (FINAL ? 0 : (size_t)NW * 32 * EBC_VN_XROW)
@@ -22,11 +22,11 @@ int launch(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, const 
       ;
   static bool raised[64] = {false};  // more than the 64 KB a launch gets by default; a function attribute is per device
   if (lds > 65536 && !raised[device & 63]) {
-    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH, GROUP, FINAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipFuncSetAttribute((const void *)ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH, GROUP, FINAL, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     raised[device & 63] = true;
   }
   const dim3 grid((unsigned)((M + 32 * NW - 1) / (32 * NW))), block(64 * NW);
-  hipLaunchKernelGGL((ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH, GROUP, FINAL>), grid, block, lds, st, M, L1, L2, y, O, ex, relu_out);
+  hipLaunchKernelGGL((ebc::mlp2_stream_kernel<TI, TH, TO, NW, KIN, KH, GROUP, FINAL, ROWS>), grid, block, lds, st, M, L1, L2, y, O, ex, relu_out, x, K0);
   HIP_TRY(hipGetLastError());
   return EBC_OK;
 }
@@ -44,9 +44,16 @@ int launch_k(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, cons
 }  // namespace
 
 int vn_stream_launch(int device, hipStream_t st, int M, const ebc::PackedLayer &L1, const ebc::PackedLayer &L2, int K0, int H, int O,
-                     float *y, const ebc::MlpExtra &ex, int relu_out) {
+                     float *y, const ebc::MlpExtra &ex, int relu_out, const float *x) {
   static const bool off = [] { const char *e = getenv("EBCSIM_VN_STREAM"); return e && atoi(e) == 0; }();  // measurements: the general block
-  if (off || !ex.frag_in || ex.frag_out) return EBC_VN_STREAM_NA;
+  if (off) return EBC_VN_STREAM_NA;
+  // `mlp1` as SarlValueNet calls it: observation rows in, its output as the consumers' fragments and as masked pair sums
+  if (!ex.frag_in && x && L1.in_tiles == 1 && K0 > 16 && L1.out_tiles == 10 && L2.out_tiles == 7 && !ex.row_bias && !ex.final_w &&
+      ex.partial && !y && !ex.store_y && ex.seg_rows >= 16 && (O & 3) == 0) {
+    if (H <= 32 * 10 - 16) return launch<1, 10, 7, 0, 1, false, false, true>(device, st, M, L1, L2, O, y, ex, relu_out, x, K0);
+    return launch<1, 10, 7, 0, 0, false, false, true>(device, st, M, L1, L2, O, y, ex, relu_out, x, K0);
+  }
+  if (!ex.frag_in || ex.frag_out) return EBC_VN_STREAM_NA;
   if (L1.in_tiles != 7 || L1.out_tiles != 7) return EBC_VN_STREAM_NA;
   // the attention block as SarlValueNet calls it: fragment input, the pair's group term, a one-output third layer
   if (ex.row_bias && ex.final_w && !ex.partial && y && L2.out_tiles == 7) {

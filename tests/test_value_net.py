@@ -356,3 +356,48 @@ def test_streamed_feature_block_equals_the_general_block_to_rounding():
             assert es <= max(2.0 * eg, 1e-5 * max(1.0, float(ref.abs().max()))), (K0, H, O, B, es, eg)
             if B > 40:
                 assert torch.equal(out[False][7], out[False][33])
+
+
+@pytest.mark.gpu
+def test_streamed_first_block_equals_the_general_block_to_rounding():
+    """`mlp1` (observation rows -> 300 -> 200: one input tile, ten hidden, seven output tiles) as the streamed kernel:
+    its output leaves as the consumers' fragments and as masked pair sums.  Against the general block (another order of
+    the hidden sums: last bits differ) and a float64 evaluation of the same rows; ragged pairs, a last tile that is not
+    full; whole copies of a pair get bit-identical fragments' sums."""
+    from ebcsim.sarl import SarlValueNet, _NativeMlp2
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(13)
+    R, K0, H, O = 18, 17, 300, 200
+
+    def lin(o, i):
+        return torch.randn(o, i, generator=g) / i ** 0.5, torch.randn(o, generator=g)
+    w1, w2 = lin(H, K0), lin(O, H)
+    blk = _NativeMlp2([w1, w2], 0)
+    for B in (700, 29, 1):
+        M = B * R
+        x = torch.randn(M, K0, generator=g)
+        if B > 40:
+            x[35 * R:36 * R] = x[9 * R:10 * R]
+        nv = torch.randint(12, R + 1, (B,), generator=g)
+        mask = (torch.arange(R)[None, :] < nv[:, None]).float().reshape(M)
+        if B > 40:
+            mask[35 * R:36 * R] = mask[9 * R:10 * R]
+        xd, md = x.to(dev), mask.to(dev)
+        out = {}
+        for general in (False, True):
+            frag = _NativeMlp2.frag_buffer(M, O, dev)
+            frag.zero_()
+            _, part = blk.forward_ex(M, True, x=xd, want_y=False, seg_rows=R, row_weight=md, want_partial=True, frag_out=frag, general=general)
+            f = frag.view(torch.bfloat16).float()                      # [tile][column tile][k-step][hi, lo][lane][8]
+            out[general] = (SarlValueNet._pair_combine(part, None, B, R, False), f[:, :, :, 0] + f[:, :, :, 1])
+        torch.cuda.synchronize()
+        h = torch.relu(torch.nn.functional.linear(x.double(), w1[0].double(), w1[1].double()))
+        yref = torch.relu(torch.nn.functional.linear(h, w2[0].double(), w2[1].double()))
+        ref = (yref * mask.double()[:, None]).view(B, R, O).sum(1)
+        es, eg = float((out[False][0].double().cpu() - ref).abs().max()), float((out[True][0].double().cpu() - ref).abs().max())
+        assert es <= max(2.0 * eg, 1e-5 * max(1.0, float(ref.abs().max()))), (B, es, eg)
+        d = float((out[False][1] - out[True][1]).abs().max())
+        assert d <= 2e-5 * max(1.0, float(out[True][1].abs().max())), (B, d)
+        assert float(out[False][1].abs().max()) > 0
+        if B > 40:
+            assert torch.equal(out[False][0][9], out[False][0][35])
