@@ -417,19 +417,28 @@ class SarlValueNet(object):
             self.coarse_eps = float(eps)
         elif getattr(self, "coarse_eps", None) is None:
             self.calibrate_eps(rows.reshape(E * A, R, T), None if n_valid is None else n_valid.repeat_interleave(A))
-        st = self.__dict__.setdefault("refine_stats", {"decisions": 0, "candidates": 0, "over2": 0, "capped": 0, "max_set": 0,
-                                                       "bound_violations": 0})
+        st = self.__dict__.setdefault("_refine_host", {"decisions": 0, "candidates": 0, "over2": 0, "capped": 0, "max_set": 0,
+                                                       "bound_violations": 0, "contested": 0})
         k = min(self.REFINE_CAP, A)
         top = torch.topk(values, k, dim=1)                                       # [E, k], best first
+        ar = np.arange(E)
         for attempt in range(4):
             bound = 2.0 * float(discount) * self.coarse_eps
-            near = top.values >= (top.values[:, :1] - bound)                     # the candidates that could be the float32 best
+            # the candidates that could be the float32 best: a PREFIX of every env's sorted row, so the set is its length.
+            # The lengths go to the host in one 8 KB copy — the one host round trip of the selection — and the index
+            # lists and the counters are made there: torch.nonzero plus four .item() reads were five round trips with an
+            # idle GPU and a dozen launch-bound little kernels behind each.
+            count = (top.values >= (top.values[:, :1] - bound)).sum(1).cpu().numpy()
             # an env with ONE candidate is decided: every other action's float32 value lies below that one's
-            contested = near & (near.sum(1, keepdim=True) > 1)
-            env_i, slot = torch.nonzero(contested, as_tuple=True)                # one host sync per decision batch
-            if env_i.numel() == 0:
+            sizes = np.where(count > 1, count, 0)
+            n_cand = int(sizes.sum())
+            if n_cand == 0:
                 exact = None
                 break
+            env_h = np.repeat(ar, sizes)
+            slot_h = np.arange(n_cand) - np.repeat(np.cumsum(sizes) - sizes, sizes)
+            idx = torch.from_numpy(np.stack([env_h, slot_h])).to(rows.device, non_blocking=True)
+            env_i, slot = idx[0], idx[1]
             act_i = top.indices[env_i, slot]
             nv = None if n_valid is None else n_valid[env_i]
             exact = self.forward(rows[env_i, act_i], nv, exact=True)
@@ -440,16 +449,22 @@ class SarlValueNet(object):
             if not worst <= self.COARSE_EPS_MAX:
                 raise RuntimeError("SarlValueNet: matrix-core values off by %.2e: not fit to rank this network's values" % worst)
             self.coarse_eps = self.EPS_MARGIN * worst
-        count = near.sum(1)
+        if exact is not None:
+            values[env_i, act_i] = reward[env_i, act_i] + discount * exact.to(torch.float64)
         st["decisions"] += E
-        st["candidates"] += int(env_i.numel())
-        st["contested"] = st.get("contested", 0) + int((count > 1).sum())
+        st["candidates"] += n_cand
+        st["contested"] += int((count > 1).sum())
         st["over2"] += int((count > 2).sum())
         st["capped"] += int((count >= k).sum()) if k < A else 0
         st["max_set"] = max(st["max_set"], int(count.max()))
-        if exact is not None:
-            values[env_i, act_i] = reward[env_i, act_i] + discount * exact.to(torch.float64)
         return values
+
+    @property
+    def refine_stats(self):
+        """Counters of the bound-driven re-evaluation since the network was made: decisions, re-evaluated candidates, envs
+        with more than one / more than two candidates, sets cut at REFINE_CAP, the largest set, bound violations."""
+        st = self.__dict__.get("_refine_host")
+        return None if st is None else dict(st)
 
     def _forward(self, rows, n_valid=None, want_weights=False, exact=False):
         B, R, T = rows.shape

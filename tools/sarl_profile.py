@@ -24,7 +24,13 @@ def main():
     env = BatchedEnv(params, E, batch.N, batch.S)
     env.reset(batch)
     env.use_torch_stream()
-    net = SarlValueNet.load(os.path.join(ROOT, "tests", "golden", "weights", which + ".pth"), device="cuda")
+    if which == "random":  # the bench's decision leg: the x2 architecture with random-init weights
+        from ebcsim.train import SarlModule
+        torch.manual_seed(0)
+        mod = SarlModule(env.T, [300, 200], [200, 100], [300, 200, 200, 1], [200, 200, 1])
+        net = SarlValueNet({k: v.detach() for k, v in mod.state_dict().items()}, device="cuda")
+    else:
+        net = SarlValueNet.load(os.path.join(ROOT, "tests", "golden", "weights", which + ".pth"), device="cuda")
     net.frag_handoff = os.environ.get("EBCSIM_FRAG_HANDOFF", "1") != "0"
     net.CHUNK_STREAMS = int(os.environ.get("EBCSIM_CHUNK_STREAMS", net.CHUNK_STREAMS))  # 1: per-kernel times without overlap
     space = actions.build_action_space(float(batch.robot[0, 7]))
