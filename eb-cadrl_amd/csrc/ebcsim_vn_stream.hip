@@ -67,3 +67,53 @@ int vn_stream_launch(int device, hipStream_t st, int M, const ebc::PackedLayer &
 }
 
 }  // namespace ebc_host
+
+// ---- the selection side of a decision: values, each env's actions by value, the size of its near-best set ------------
+namespace ebc {
+
+// One workgroup per env.  Ranking by counting (A <= 1024 values in LDS: action i's rank = the number of actions with a
+// larger value, or the same value and a lower index): a full sort of every env's row, a dozen element-wise launches and a
+// sort in torch before.
+__global__ __launch_bounds__(128) void decision_rank_kernel(const float *v, const double *reward, double discount, double bound, int A,
+                                                             double *values, int *order, int *count) {
+  __shared__ double vals[1024];
+  __shared__ int near;
+  const int e = blockIdx.x;
+  if (threadIdx.x == 0) near = 0;
+  for (int i = threadIdx.x; i < A; i += blockDim.x) {
+    const double x = reward[(size_t)e * A + i] + discount * (double)v[(size_t)e * A + i];
+    vals[i] = x;
+    values[(size_t)e * A + i] = x;
+    order[(size_t)e * A + i] = i;  // (a NaN among the values leaves ranks unassigned: every entry stays a valid action)
+  }
+  __syncthreads();
+  int mine = 0;
+  for (int i = threadIdx.x; i < A; i += blockDim.x) {
+    const double x = vals[i];
+    int rank = 0;
+    for (int j = 0; j < A; ++j) rank += (vals[j] > x || (vals[j] == x && j < i)) ? 1 : 0;
+    order[(size_t)e * A + rank] = i;
+  }
+  // the best value is the one of rank 0: found again by a max over the row (cheap), then the near-best count
+  double best = vals[0];
+  for (int j = 1; j < A; ++j) best = vals[j] > best ? vals[j] : best;
+  const double floor_ = best - bound;
+  for (int i = threadIdx.x; i < A; i += blockDim.x) mine += vals[i] >= floor_ ? 1 : 0;
+  atomicAdd(&near, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) count[e] = near;
+}
+
+}  // namespace ebc
+
+extern "C" int ebc_decision_rank(void *stream, const float *v, const double *reward, double discount, double bound, int E, int A,
+                                 double *values, int32_t *order, int32_t *count) {
+  if (!v || !reward || !values || !order || !count || E < 0 || A <= 0 || A > 1024)
+    return ebc_host::fail(EBC_ERR_INVALID, "decision_rank arguments (1 <= A <= 1024)");
+  if (E == 0) return EBC_OK;
+  hipLaunchKernelGGL(ebc::decision_rank_kernel, dim3((unsigned)E), dim3(128), 0, (hipStream_t)stream, v, reward, discount, bound, A, values,
+                     order, count);
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
+

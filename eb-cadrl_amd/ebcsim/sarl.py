@@ -402,7 +402,23 @@ class SarlValueNet(object):
                 v[e0:e1] = self.forward(rows[e0:e1].reshape(-1, R, T), nv).view(e1 - e0, A)
         for s_ in side:
             main.wait_stream(s_)
-        values = reward + discount * v.to(torch.float64)
+        native_select = rows.is_cuda and self._native_blocks() is not None and refine is None
+        if native_select:
+            if eps is not None:
+                self.coarse_eps = float(eps)
+            elif getattr(self, "coarse_eps", None) is None:
+                self.calibrate_eps(rows.reshape(E * A, R, T), None if n_valid is None else n_valid.repeat_interleave(A))
+            # values, every env's actions by value and the size of its near-best set in ONE launch (ebc_decision_rank)
+            from . import _capi
+            values = torch.empty((E, A), dtype=torch.float64, device=rows.device)
+            order = torch.empty((E, A), dtype=torch.int32, device=rows.device)
+            count_dev = torch.empty((E,), dtype=torch.int32, device=rows.device)
+            reward = reward.to(torch.float64).contiguous()
+            _capi.check(_capi.lib().ebc_decision_rank(torch.cuda.current_stream(rows.device).cuda_stream, v.data_ptr(), reward.data_ptr(),
+                                                      float(discount), 2.0 * float(discount) * self.coarse_eps, E, A,
+                                                      values.data_ptr(), order.data_ptr(), count_dev.data_ptr()))
+        else:
+            values = reward + discount * v.to(torch.float64)
         if not (rows.is_cuda and self._native_blocks() is not None) or refine == 0:
             return values
         if refine is not None:
@@ -420,7 +436,6 @@ class SarlValueNet(object):
         st = self.__dict__.setdefault("_refine_host", {"decisions": 0, "candidates": 0, "over2": 0, "capped": 0, "max_set": 0,
                                                        "bound_violations": 0, "contested": 0})
         k = min(self.REFINE_CAP, A)
-        top = torch.topk(values, k, dim=1)                                       # [E, k], best first
         ar = np.arange(E)
         for attempt in range(4):
             bound = 2.0 * float(discount) * self.coarse_eps
@@ -428,7 +443,12 @@ class SarlValueNet(object):
             # The lengths go to the host in one 8 KB copy — the one host round trip of the selection — and the index
             # lists and the counters are made there: torch.nonzero plus four .item() reads were five round trips with an
             # idle GPU and a dozen launch-bound little kernels behind each.
-            count = (top.values >= (top.values[:, :1] - bound)).sum(1).cpu().numpy()
+            if attempt == 0:
+                count = count_dev.cpu().numpy().astype(np.int64)
+            else:  # the bound was widened: the sizes again, from the ranked values
+                ranked = values.gather(1, order.to(torch.int64))
+                count = (ranked >= (ranked[:, :1] - bound)).sum(1).cpu().numpy()
+            count = np.minimum(count, k)
             # an env with ONE candidate is decided: every other action's float32 value lies below that one's
             sizes = np.where(count > 1, count, 0)
             n_cand = int(sizes.sum())
@@ -439,7 +459,7 @@ class SarlValueNet(object):
             slot_h = np.arange(n_cand) - np.repeat(np.cumsum(sizes) - sizes, sizes)
             idx = torch.from_numpy(np.stack([env_h, slot_h])).to(rows.device, non_blocking=True)
             env_i, slot = idx[0], idx[1]
-            act_i = top.indices[env_i, slot]
+            act_i = order[env_i, slot].to(torch.int64)
             nv = None if n_valid is None else n_valid[env_i]
             exact = self.forward(rows[env_i, act_i], nv, exact=True)
             worst = float((exact - v[env_i, act_i]).abs().max())                # the bound, checked where it matters

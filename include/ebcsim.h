@@ -469,6 +469,15 @@ int ebc_mlp2_forward_f32(void *mlp, void *stream, const float *x, int M, int rel
 int ebc_mlp2_forward_reduce(void *mlp, void *stream, const float *x, int M, int relu_out, const float *row_bias,
                             int group_rows, float *y, int seg_rows, const float *row_weight, double *partial);
 int ebc_pair_weights(void *stream, const float *scores, const long long *n_valid, int B, int R, float *w);
+
+/* The argmax side of MultiHumanRL.predict for a batch (rl/policy/multi_human_rl.py:72-80), one launch:
+ *   values [E][A] (float64) = reward + discount * v      (v [E][A]: the value network's float32 outputs)
+ *   order  [E][A] (int32)   = each env's actions by value, best first (equal values: the lower action index first)
+ *   count  [E]    (int32)   = how many of them lie within `bound` of the env's best: the prefix of `order` that can
+ *                             hold the float32 network's best action when the values carry an error of bound / 2
+ * Device pointers; A <= 1024.  (What ebcsim.sarl.SarlValueNet.action_values selects its re-evaluated candidates from.) */
+int ebc_decision_rank(void *stream, const float *v, const double *reward, double discount, double bound, int E, int A,
+                      double *values, int32_t *order, int32_t *count);
 int ebc_pair_mask(void *stream, const long long *n_valid, int B, int R, float *w);
 int ebc_pair_combine(void *stream, const double *partial, const long long *n_valid, int B, int R, int O, int mean,
                      float *out);

@@ -289,3 +289,35 @@ def test_batches_whose_robots_differ_in_v_pref_are_refused():
     assert uniform_v_pref(Env([1.0, 1.0, 1.0])) == 1.0
     with pytest.raises(ValueError, match="v_pref"):
         uniform_v_pref(Env([1.0, 1.2, 1.0]))
+
+
+@pytest.mark.gpu
+def test_decision_rank_kernel_against_torch():
+    """ebc_decision_rank (one launch: values, every env's actions by value, the size of the near-best set) against the
+    torch expressions it replaces: the same float64 values bit for bit, a permutation per env that sorts them (equal
+    values: the lower action first), the same counts — with exact ties in the rows."""
+    import torch
+    from ebcsim import _capi
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    for E, A in ((1024, 81), (3, 1), (17, 200)):
+        v = torch.randn(E, A, generator=g)
+        v[:, A // 2] = v[:, 0]                      # an exact tie in every row
+        reward = torch.randn(E, A, generator=g, dtype=torch.float64) * 0.1
+        reward[:, A // 2] = reward[:, 0]
+        v, reward = v.to(dev), reward.to(dev)
+        discount, bound = 0.9 ** 0.25, 0.05
+        values = torch.empty((E, A), dtype=torch.float64, device=dev)
+        order = torch.empty((E, A), dtype=torch.int32, device=dev)
+        count = torch.empty((E,), dtype=torch.int32, device=dev)
+        _capi.check(_capi.lib().ebc_decision_rank(torch.cuda.current_stream(dev).cuda_stream, v.data_ptr(), reward.data_ptr(), discount, bound,
+                                                  E, A, values.data_ptr(), order.data_ptr(), count.data_ptr()))
+        ref = reward + discount * v.to(torch.float64)
+        assert torch.equal(values, ref)
+        o = order.to(torch.int64)
+        assert torch.equal(o.sort(1).values, torch.arange(A, device=dev).expand(E, A))
+        ranked = ref.gather(1, o)
+        assert bool((ranked[:, 1:] <= ranked[:, :-1]).all())
+        tie = ranked[:, 1:] == ranked[:, :-1]
+        assert bool((o[:, 1:][tie] > o[:, :-1][tie]).all()) and int(tie.sum()) >= (E if A > 1 else 0)
+        assert torch.equal(count.to(torch.int64), (ref >= (ref.max(1, keepdim=True).values - bound)).sum(1))
