@@ -104,7 +104,40 @@ __global__ __launch_bounds__(128) void decision_rank_kernel(const float *v, cons
   if (threadIdx.x == 0) count[e] = near;
 }
 
+// values[env][act] = reward + discount * exact for the re-evaluated candidates; the largest |exact - coarse| among them
+// (non-negative floats order like their bit patterns: an atomic max on the bits; a NaN lands above every bound)
+__global__ __launch_bounds__(256) void decision_apply_kernel(const float *exact, const float *v, const long long *env, const long long *act,
+                                                              const double *reward, double discount, int A, int n, double *values,
+                                                              unsigned *worst_bits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float d = 0.0f;
+  if (i < n) {
+    const size_t at = (size_t)env[i] * A + (size_t)act[i];
+    const float x = exact[i];
+    d = fabsf(x - v[at]);
+    values[at] = reward[at] + discount * (double)x;
+  }
+  unsigned bits = __float_as_uint(d);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned other = __shfl_xor(bits, o, 64);
+    bits = other > bits ? other : bits;
+  }
+  if ((threadIdx.x & 63) == 0 && bits) atomicMax(worst_bits, bits);
+}
+
 }  // namespace ebc
+
+extern "C" int ebc_decision_apply(void *stream, const float *exact, const float *v, const long long *env, const long long *act,
+                                  const double *reward, double discount, int A, int n, double *values, float *worst) {
+  if (!exact || !v || !env || !act || !reward || !values || !worst || A <= 0 || n < 0)
+    return ebc_host::fail(EBC_ERR_INVALID, "decision_apply arguments");
+  if (n == 0) return EBC_OK;
+  hipLaunchKernelGGL(ebc::decision_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, exact, v, env, act, reward,
+                     discount, A, n, values, reinterpret_cast<unsigned *>(worst));
+  HIP_TRY(hipGetLastError());
+  return EBC_OK;
+}
 
 extern "C" int ebc_decision_rank(void *stream, const float *v, const double *reward, double discount, double bound, int E, int A,
                                  double *values, int32_t *order, int32_t *count) {

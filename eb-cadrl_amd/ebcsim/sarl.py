@@ -461,16 +461,20 @@ class SarlValueNet(object):
             env_i, slot = idx[0], idx[1]
             act_i = order[env_i, slot].to(torch.int64)
             nv = None if n_valid is None else n_valid[env_i]
-            exact = self.forward(rows[env_i, act_i], nv, exact=True)
-            worst = float((exact - v[env_i, act_i]).abs().max())                # the bound, checked where it matters
+            exact = self.forward(rows[env_i, act_i], nv, exact=True).to(torch.float32).contiguous()
+            # the candidates' float32 values into `values`, and the bound checked where it matters: one launch, one read
+            # (a widened bound below selects a superset and applies again)
+            worst_dev = torch.zeros(1, dtype=torch.float32, device=rows.device)
+            _capi.check(_capi.lib().ebc_decision_apply(torch.cuda.current_stream(rows.device).cuda_stream, exact.data_ptr(), v.data_ptr(),
+                                                       env_i.contiguous().data_ptr(), act_i.contiguous().data_ptr(), reward.data_ptr(),
+                                                       float(discount), A, n_cand, values.data_ptr(), worst_dev.data_ptr()))
+            worst = float(worst_dev)
             if worst <= self.coarse_eps:
                 break
             st["bound_violations"] += 1
             if not worst <= self.COARSE_EPS_MAX:
                 raise RuntimeError("SarlValueNet: matrix-core values off by %.2e: not fit to rank this network's values" % worst)
             self.coarse_eps = self.EPS_MARGIN * worst
-        if exact is not None:
-            values[env_i, act_i] = reward[env_i, act_i] + discount * exact.to(torch.float64)
         st["decisions"] += E
         st["candidates"] += n_cand
         st["contested"] += int((count > 1).sum())

@@ -478,6 +478,12 @@ int ebc_pair_weights(void *stream, const float *scores, const long long *n_valid
  * Device pointers; A <= 1024.  (What ebcsim.sarl.SarlValueNet.action_values selects its re-evaluated candidates from.) */
 int ebc_decision_rank(void *stream, const float *v, const double *reward, double discount, double bound, int E, int A,
                       double *values, int32_t *order, int32_t *count);
+/* The re-evaluated candidates back into the values, one launch: for i < n, values[env[i]][act[i]] = reward[env[i]][act[i]] +
+ * discount * exact[i] (exact: the float32 network's values of the n candidates; env / act: int64 indices), and
+ * *worst (float, zeroed by the caller) = max_i |exact[i] - v[env[i]][act[i]]| — the error of the matrix-core values
+ * where it matters, which the caller holds against its bound.  Device pointers. */
+int ebc_decision_apply(void *stream, const float *exact, const float *v, const long long *env, const long long *act,
+                       const double *reward, double discount, int A, int n, double *values, float *worst);
 int ebc_pair_mask(void *stream, const long long *n_valid, int B, int R, float *w);
 int ebc_pair_combine(void *stream, const double *partial, const long long *n_valid, int B, int R, int O, int mean,
                      float *out);

@@ -321,3 +321,28 @@ def test_decision_rank_kernel_against_torch():
         tie = ranked[:, 1:] == ranked[:, :-1]
         assert bool((o[:, 1:][tie] > o[:, :-1][tie]).all()) and int(tie.sum()) >= (E if A > 1 else 0)
         assert torch.equal(count.to(torch.int64), (ref >= (ref.max(1, keepdim=True).values - bound)).sum(1))
+
+
+@pytest.mark.gpu
+def test_decision_apply_kernel_against_torch():
+    """ebc_decision_apply against the torch expressions it replaces: the candidates' values written where they belong
+    (bit for bit reward + discount * exact), everything else untouched, and the largest |exact - coarse| among them."""
+    import torch
+    from ebcsim import _capi
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(6)
+    E, A = 300, 81
+    v = torch.randn(E, A, generator=g).to(dev)
+    reward = (torch.randn(E, A, generator=g, dtype=torch.float64) * 0.1).to(dev)
+    for n in (1, 77, 5000):
+        flat = torch.randperm(E * A, generator=g)[:n].sort().values.to(dev)
+        env_i, act_i = flat // A, flat % A
+        exact = (v[env_i, act_i] + 1e-3 * torch.randn(n, generator=g).to(dev)).contiguous()
+        values = (reward + 0.9 * v.to(torch.float64)).contiguous()
+        ref = values.clone()
+        ref[env_i, act_i] = reward[env_i, act_i] + 0.9 * exact.to(torch.float64)
+        worst = torch.zeros(1, dtype=torch.float32, device=dev)
+        _capi.check(_capi.lib().ebc_decision_apply(torch.cuda.current_stream(dev).cuda_stream, exact.data_ptr(), v.data_ptr(), env_i.data_ptr(),
+                                                   act_i.data_ptr(), reward.data_ptr(), 0.9, A, n, values.data_ptr(), worst.data_ptr()))
+        assert torch.equal(values, ref)
+        assert float(worst) == float((exact - v[env_i, act_i]).abs().max())
