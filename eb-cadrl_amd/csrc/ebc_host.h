@@ -1,5 +1,6 @@
 // ebc_host.h — host-side helpers shared by the translation units of libebcsim.so (ebcsim.hip: the simulation path;
-// ebcsim_value_net.hip: the value-network blocks — two units so that they compile side by side).
+// ebcsim_value_net.hip: the value-network blocks; ebcsim_vn_stream.hip: the streamed blocks — units that compile side
+// by side).
 #pragma once
 
 #include <hip/hip_runtime.h>

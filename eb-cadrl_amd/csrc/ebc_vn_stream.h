@@ -1,24 +1,28 @@
-// ebc_vn_stream.h — the attention block of the SARL value network (/root/reference/rl/policy/sarl.py:61-72:
-// attention = mlp(cat([h1, g]), [.., .., 1])) for the widest shapes, streamed.
+// ebc_vn_stream.h — the wide blocks of the SARL value network (/root/reference/rl/policy/sarl.py:38-82: `mlp1` on the
+// observation rows, the attention stack mlp(cat([h1, g]), [.., .., 1]), `mlp2`), streamed.
 //
 // The general block (mlp2_split_wg_kernel, ebc_value_net.h) keeps a wave's INPUT fragments in registers across all
-// hidden tiles.  At 7 input + 7 output tiles that is 104 + 112 registers before anything else: the compiler spilled 21
-// of them, and every reload inside the loop is an `s_waitcnt vmcnt(0)` that also waits for the weight staging in
-// flight behind it (one in-order counter) — the matrix pipe sat at 26 % busy (profiles/r03_value_net_pmc.txt).
+// hidden tiles.  At 7 input + 7 output tiles (the attention stack) that is 104 + 112 registers before anything else: the
+// compiler spilled 21 of them, and every reload inside the loop is an `s_waitcnt vmcnt(0)` that also waits for the
+// weight staging in flight behind it (one in-order counter) — the matrix pipe sat at 26 % busy.
 //
 // Here the loops are turned inside out so that nothing wide stays resident:
 //   phase A, one PERIOD per input tile i: hacc[u] += W1[u][i] . x[i] for ALL hidden tiles u (TH accumulators; the
 //     input fragments of one tile are loaded, used for 3 TH instructions and dropped);
-//   phase B: bias (in the accumulators from the start) + the pair's group term, ReLU, split: the TH hidden tiles
-//     become the 2 TH fragments of the second layer, in place;
-//   phase C, one period per output tile t: out = W2[t][.] . hid over all hidden tiles, then the one-output third
-//     layer's share of that tile at once (out is one accumulator, not TO of them).
-// Every period multiplies one 28 KB SLAB of weights (TH fragments x 2 k-steps x hi/lo), the same for all waves of the
-// workgroup: slabs arrive by LDS-DMA two periods ahead into a ring of three; input fragments come from the hand-off
-// tensor (MlpExtra.frag_in: already split, already in fragment order) by plain 16-byte loads hidden in asm, two
-// periods ahead into a ring of three register sets.  ONE barrier per period, in front of it ONE counted wait that
-// leaves the newest period's loads in flight.  Products and sums per output are those of the general block, in the
-// same order: the two kernels agree bit for bit (tests/test_value_net.py).
+//   phase B: bias (in the accumulators from the start) [+ the pair's group term: GROUP], ReLU, split: the TH hidden
+//     tiles become the 2 TH fragments of the second layer, in place;
+//   phase C, one period per output tile t: out = W2[t][.] . hid over all hidden tiles (ONE accumulator, not TO of them),
+//     and the tile is finished on the spot: FINAL — the one-output third layer's share of it (the attention scores);
+//     else the general block's tile epilogue — the tile as the next block's fragments (MlpExtra.frag_out) and / or its
+//     weighted pair sums (MlpExtra.partial), its rows never written (`mlp1`, `mlp2`).
+// Every period multiplies one SLAB of weights (TH fragments x 2 k-steps x hi/lo: 28 KB at 7 hidden tiles), the same
+// for all waves of the workgroup: slabs arrive by LDS-DMA two periods ahead into a ring of three; input fragments come
+// from the hand-off tensor (MlpExtra.frag_in: already split, already in fragment order) by plain 16-byte loads hidden in
+// asm, two periods ahead into a ring of three register sets — or, ROWS, from float32 rows split by the lanes in the
+// head (one input tile).  ONE barrier per period, in front of it ONE counted wait that leaves the newest period's loads
+// in flight.  With GROUP and FINAL the products and sums per output are those of the general block in the same order:
+// bit-equal scores; the other two forms add their hidden tiles up in one chain where the general block alternates two
+// accumulators: equal to rounding (tests/test_value_net.py).  Measurements: DESIGN.md section 3 item 18.
 #pragma once
 
 #include "ebc_vn_common.h"

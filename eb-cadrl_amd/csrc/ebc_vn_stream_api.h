@@ -1,5 +1,5 @@
-// ebc_vn_stream_api.h — host entry of the streamed attention block (ebcsim_vn_stream.hip; its own translation unit so
-// that it compiles beside the others).
+// ebc_vn_stream_api.h — host entry of the streamed value-network blocks (ebcsim_vn_stream.hip; its own translation unit
+// so that it compiles beside the others).
 #pragma once
 
 #include "ebc_host.h"

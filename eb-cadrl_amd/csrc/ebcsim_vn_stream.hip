@@ -1,4 +1,6 @@
-// ebcsim_vn_stream.hip — launch of the streamed attention block (ebc_vn_stream.h) for the shapes it is built for.
+// ebcsim_vn_stream.hip — launch of the streamed value-network blocks (ebc_vn_stream.h) for the shapes they are built
+// for, and the two small kernels of a decision's selection side (ebc_decision_rank, ebc_decision_apply).  Its own
+// translation unit: seconds to compile beside the general blocks' minutes.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
